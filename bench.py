@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""Benchmark of the three-stage ray tracer on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+
+A step is one whole frame (or one batch of views): raygen, then P x {intersect, color},
+with the scene already resident in HBM, plus -- for N > 1 -- the gather of the RGBA8 rows
+to rank 0 over RCCL.  One process per GPU (torch.distributed, backend nccl); one frame is
+cut into interleaved row tiles over the ranks, so the total work is fixed ("strong").
+
+value = rays actually traced (closest-hit rays entering traversal + shadow rays traced,
+summed over passes and ranks) per second of wall time, in Mrays/s.  Rays that missed
+everything are dead (the reference skips them in intersect; in color they provably shade
+to the background grey, so no shadow ray is traced for them and none is counted).
+
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_TEST = 52.0          # Moller-Trumbore as the reference writes it (trace.glsl:5-20)
+PEAK_FP32_TFLOPS = 157.3      # MI355X vector FP32 peak
+METRIC = "Mrays/s (primary+secondary) at 4K vs triangle count; % FP32 VALU peak"
+
+
+def workload(name):
+    from opengl_raytracer_amd import scenes
+    if name == "soup64k_4k_p6":
+        return dict(kind="tiles", width=3840, height=2160, passes=6, lights=1,
+                    mesh=scenes.triangle_soup(65536, seed=12345), tex=scenes.noise_texture(256, 256),
+                    cams=[(np.float32([0, 0, -3]), np.float32([0, 0, 1]), np.float32([0, 1, 0]),
+                           np.float32([1, 0, 0]))],
+                    desc="synthetic soup, 65536 triangles (seed 12345), 3840x2160, 6 passes (5 bounces), 1 light")
+    if name == "soup256k_64views_1080p":
+        cams = [scenes.look_at_camera((3.0 * np.cos(a), 0.0, 3.0 * np.sin(a)), (0, 0, 0))
+                for a in 2 * np.pi * np.arange(64) / 64]
+        return dict(kind="views", width=1920, height=1080, passes=1, lights=1,
+                    mesh=scenes.triangle_soup(262144, seed=12346), tex=scenes.noise_texture(256, 256), cams=cams,
+                    desc="synthetic soup, 262144 triangles (seed 12346), 64 views of 1920x1080, 1 pass, 1 light")
+    if name == "blob28k_1080p_p1":
+        return dict(kind="tiles", width=1920, height=1080, passes=1, lights=1, mesh=scenes.blob(),
+                    tex=scenes.noise_texture(256, 256), cams=[scenes.look_at_camera((0.4, 0.3, -1.8), (0, 0, 0))],
+                    desc="28576-triangle closed blob (stand-in for the absent bunny.obj), 1920x1080, 1 pass, 1 light")
+    if name == "blobsword_4k_p4":
+        sword = scenes.quad_grid(11, 7, origin=(-0.1, -1.2, -1.0), du=(0.2, 0.0, 0.05), dv=(0.0, 2.4, 0.1))
+        sword = np.concatenate([sword, sword[:33]])  # 154 + 11 = 165 triangles, like sword_fixed
+        return dict(kind="tiles", width=3840, height=2160, passes=4, lights=1,
+                    mesh=scenes.concat_meshes(scenes.blob(), sword), tex=scenes.noise_texture(1024, 1024),
+                    cams=[scenes.look_at_camera((0.4, 0.3, -1.8), (0, 0, 0))],
+                    desc="28576-triangle blob + 165-triangle blade (stand-ins for bunny + sword), 3840x2160, "
+                         "4 passes (3 bounces), 1 light, 1024x1024 texture")
+    raise SystemExit(f"unknown workload {name}")
+
+
+def setup_scene(obj, wl):
+    from opengl_raytracer_amd import scenes
+    obj.set_mesh(wl["mesh"])
+    obj.set_texture(wl["tex"])
+    obj.set_lights(scenes.default_lights(), wl["lights"])
+    obj.set_camera(*wl["cams"][0])
+
+
+def cpu_baseline(wl, seconds_hint=15.0):
+    """The oracle (a port of the reference's shaders) on the host cores, on a bounded sample:
+    the same scene and camera at 1/10 of the width and height (1/100 of the rays)."""
+    from oracle.rt_oracle import Oracle
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    threads = max(1, min(threads, 64))
+    w, h = max(1, wl["width"] // 10), max(1, wl["height"] // 10)
+    o = Oracle(w, h, threads=threads)
+    setup_scene(o, wl)
+    rays = 0
+    t0 = time.perf_counter()
+    n_views = 0
+    for cam in wl["cams"]:
+        o.set_camera(*cam)
+        o.raygen()
+        for _ in range(wl["passes"]):
+            rays += int((o.rays["primitiveID"] != -2).sum())
+            o.intersect()
+            rays += int(np.isfinite(o.rays["origin"]).all(axis=1).sum()) * wl["lights"]
+            o.color()
+        n_views += 1
+        if time.perf_counter() - t0 > seconds_hint:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"same scene, {n_views} view(s) at {w}x{h} (1/100 of the rays per view), "
+                      f"{wl['passes']} passes, oracle with {threads} OpenMP threads, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="soup64k_4k_p6")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--trace-mode", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import opengl_raytracer_amd as rt
+    from opengl_raytracer_amd import sharding
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    if args.gpus != world and rank == 0:
+        print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+    dev = torch.device("cuda", local_rank)
+
+    wl = workload(args.workload)
+    g = rt.RayTracer(wl["width"], wl["height"], device=local_rank)
+    setup_scene(g, wl)
+    g.set_trace_mode(args.trace_mode)
+    if wl["kind"] == "tiles":
+        job = sharding.TileShardedFrame(g, wl["width"], wl["height"], dev)
+        shard_desc = f"image tiles of {job.tile_rows} rows, interleaved over {world} rank(s), gathered to rank 0"
+    else:
+        job = sharding.FrameBatch(g, wl["width"], wl["height"], wl["cams"], dev)
+        shard_desc = f"frame batch: view k on rank k % {world}, frames gathered to rank 0"
+
+    def sync_all():
+        g.sync()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        job.render(wl["passes"])
+    sync_all()
+    g.counters()
+    g.kernel_log()
+    g.stage_ms()
+
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        job.render(wl["passes"])
+    sync_all()
+    dt = time.perf_counter() - t0
+
+    cnt = g.counters()
+    log = g.kernel_log()
+    stage_ms = g.stage_ms()
+    tot = torch.tensor([cnt["closest_rays"], cnt["shadow_rays"], cnt["closest_pairs"], cnt["shadow_pairs"],
+                        cnt["closest_candidates"], cnt["shadow_candidates"]], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    tot = tot.cpu().numpy()
+    dt = float(tmax.item())
+
+    if rank == 0:
+        steps = max(args.steps, 1)
+        rays = tot[0] + tot[1]
+        # dominant kernel on rank 0: group the launch log by kernel variant
+        groups = {}
+        for r in log:
+            key = (int(r["stage"]), int(r["form"]), int(r["rays_per_lane"]), int(r["exact"]))
+            a = groups.setdefault(key, dict(ms=0.0, launches=0, pairs=0.0))
+            a["ms"] += float(r["ms"]); a["launches"] += 1; a["pairs"] += float(r["pairs"])
+        kernels = []
+        for (stage, form, k, exact), a in sorted(groups.items(), key=lambda kv: -kv[1]["ms"]):
+            pairs = a["pairs"]
+            if stage == 2:  # shadow traversal: pairs actually executed (early exit), from the counters
+                share = a["pairs"] / max(sum(x["pairs"] for kk, x in groups.items() if kk[0] == 2), 1.0)
+                pairs = cnt["shadow_pairs"] * share
+            name = ("closest_hit_kernel" if stage == 1 else "shade_kernel") + \
+                   f"<K={k},{'shared-origin' if form == 1 else 'general'}{',exact' if exact else ''}>"
+            kernels.append(dict(kernel=name, launches=a["launches"], avg_ms=a["ms"] / a["launches"],
+                                total_ms=a["ms"], pairs_per_launch=pairs / a["launches"],
+                                tflops=pairs * FLOP_PER_TEST / (a["ms"] * 1e-3) / 1e12 if a["ms"] > 0 else 0.0))
+        dom = kernels[0] if kernels else None
+        roofline = None
+        if dom:
+            roofline = {"bound": "valu", "kernel": dom["kernel"], "achieved": dom["tflops"],
+                        "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": dom["tflops"] / PEAK_FP32_TFLOPS,
+                        "traffic": None, "avg_launch_ms": dom["avg_ms"], "launches": dom["launches"],
+                        "flop_per_pair": FLOP_PER_TEST, "pairs_per_launch": dom["pairs_per_launch"],
+                        "note": "FP32 vector ALU bound (no MFMA); achieved = 52 FLOP x (ray,triangle) pairs "
+                                "per launch / launch duration from hipEvent pairs around each launch"}
+        out = {
+            "metric": METRIC, "value": rays / dt / 1e6, "unit": "Mrays/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": args.workload, "description": wl["desc"], "width": wl["width"],
+                       "height": wl["height"], "views": len(wl["cams"]), "triangles": int(wl["mesh"].shape[0] // 3),
+                       "passes": wl["passes"], "lights": wl["lights"], "sharding": shard_desc,
+                       "trace_mode": "filtered" if args.trace_mode == 0 else "exact",
+                       "rays_per_step": rays / steps,
+                       "closest_hit_rays_per_step": tot[0] / steps, "shadow_rays_per_step": tot[1] / steps,
+                       "pairs_per_step": (tot[2] + tot[3]) / steps,
+                       "filter_pass_rate": (tot[4] + tot[5]) / max(tot[2] + tot[3], 1.0)},
+            "pairs_per_s": (tot[2] + tot[3]) / dt,
+            "stage_ms_per_step_rank0": {"raygen": stage_ms[0] / steps, "intersect": stage_ms[1] / steps,
+                                        "color": stage_ms[2] / steps},
+            "roofline": roofline,
+            "kernels_rank0": kernels[:6],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(wl)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    g.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,99 @@
+"""ctypes binding of librt_hip.so (the C ABI declared in include/rt.h).
+
+There is no fallback: if the HIP library has not been built, or no gfx950 device
+is present when a context is created, this raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librt_hip.so")
+
+# Record layouts of include/rt.h ("OpenGL Raytracer/Ray.h":9-24, main.cpp:29-35, 148-167)
+RAY_DTYPE = np.dtype([
+    ("origin", "<f4", 3), ("pad0", "<f4"),
+    ("dir", "<f4", 3), ("pad1", "<f4"),
+    ("color", "<f4", 3), ("t", "<f4"),
+    ("primitiveID", "<i4"), ("pad2", "<f4", 3),
+    ("n", "<f4", 3), ("pad5", "<f4"),
+])
+VERTEX_DTYPE = np.dtype([
+    ("pos", "<f4", 3), ("pad0", "<f4"),
+    ("texCoord", "<f4", 2), ("pad1", "<f4", 2),
+])
+LIGHT_DTYPE = np.dtype([
+    ("pos", "<f4", 3), ("pad0", "<f4"),
+    ("color", "<f4", 3), ("pad1", "<f4"),
+])
+assert RAY_DTYPE.itemsize == 80 and VERTEX_DTYPE.itemsize == 32 and LIGHT_DTYPE.itemsize == 32
+
+KERNEL_RECORD_DTYPE = np.dtype([
+    ("stage", "<i4"), ("form", "<i4"), ("rays_per_lane", "<i4"), ("exact", "<i4"),
+    ("rays", "<u8"), ("pairs", "<u8"), ("ms", "<f4"), ("reserved", "<f4"),
+])
+assert KERNEL_RECORD_DTYPE.itemsize == 40
+
+RT_MAX_LIGHTS = 10
+RT_TRACE_FILTERED = 0
+RT_TRACE_EXACT = 1
+
+# every symbol include/rt.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+PROTOTYPES = {
+    "rt_create": (C.c_int, [C.POINTER(_P), C.c_int, C.c_int, C.c_int]),
+    "rt_destroy": (None, [_P]),
+    "rt_set_mesh": (C.c_int, [_P, _P, C.c_int]),
+    "rt_set_texture_rgba8": (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    "rt_set_lights": (C.c_int, [_P, _P, C.c_int]),
+    "rt_set_camera": (C.c_int, [_P, _P, _P, _P, _P]),
+    "rt_set_row_tiles": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
+    "rt_local_rows": (C.c_int, [_P]),
+    "rt_num_rays": (C.c_int, [_P]),
+    "rt_get_row_map": (C.c_int, [_P, _P]),
+    "rt_set_trace_mode": (C.c_int, [_P, C.c_int]),
+    "rt_raygen": (C.c_int, [_P]),
+    "rt_intersect": (C.c_int, [_P]),
+    "rt_color": (C.c_int, [_P]),
+    "rt_render": (C.c_int, [_P, C.c_int]),
+    "rt_sync": (C.c_int, [_P]),
+    "rt_read_rays": (C.c_int, [_P, _P]),
+    "rt_write_rays": (C.c_int, [_P, _P]),
+    "rt_read_pixels_rgba8": (C.c_int, [_P, _P]),
+    "rt_read_depth": (C.c_int, [_P, _P]),
+    "rt_stage_ms": (C.c_int, [_P, _P]),
+    "rt_get_counters": (C.c_int, [_P, _P]),
+    "rt_kernel_log": (C.c_int, [_P, _P, C.c_int, _P]),
+    "rt_bind_stream": (C.c_int, [_P, _P]),
+    "rt_unbind_stream": (C.c_int, [_P]),
+    "rt_bind_framebuffer": (C.c_int, [_P, _P]),
+    "rt_last_error": (C.c_char_p, [_P]),
+    "rt_version": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+class RtError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"rt error {code}: {message}")
+        self.code = code
+
+
+def load():
+    """Loads librt_hip.so and sets the prototypes.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `make -C opengl_raytracer_amd/csrc` "
+            "(or __graft_entry__.build()); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

@@ -1,0 +1,26 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle_mod():
+    from oracle import rt_oracle
+    rt_oracle.load()
+    return rt_oracle
+
+
+@pytest.fixture(scope="session")
+def rt():
+    """The product package; GPU tests only."""
+    import opengl_raytracer_amd as pkg
+    return pkg

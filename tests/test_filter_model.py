@@ -1,0 +1,203 @@
+"""Randomized check that the traversal filter never rejects a (ray, triangle) pair
+that the oracle's Moller-Trumbore accepts.  Runs the filter header the kernels use,
+compiled for the host (tests/native/filter_model.cpp), against the oracle."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+f32 = np.float32
+
+
+@pytest.fixture(scope="module")
+def fm():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "..", "oracle")])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "native")])
+    lib = C.CDLL(os.path.join(HERE, "native", "libfilter_model.so"))
+    P = C.c_void_p
+    lib.fm_check_general.argtypes = [C.c_int, P, C.c_int, P, P, P, C.c_float, P]
+    lib.fm_check_origin.argtypes = [C.c_int, P, C.c_int, P, P, P, P, C.c_float, P]
+    return lib
+
+
+def bounding_sphere(verts):
+    v = verts.reshape(-1, 3).astype(np.float64)
+    v = v[np.isfinite(v).all(1)]  # as rt_set_mesh does: such triangles can never be hit
+    c = (v.min(0) + v.max(0)) / 2
+    r = np.sqrt(((v - c) ** 2).sum(1).max()) * 1.0001 + 1e-30
+    return c.astype(f32), float(r)
+
+
+def tris_random(rs, n, extent, size, offset=(0, 0, 0)):
+    c = rs.uniform(-extent, extent, size=(n, 1, 3)) + np.asarray(offset)
+    return (c + rs.uniform(-size, size, size=(n, 3, 3))).astype(f32)
+
+
+def tris_nasty(rs, n, extent):
+    """needles, slivers, huge and tiny triangles mixed"""
+    t = tris_random(rs, n, extent, 0.1).astype(np.float64)
+    kind = rs.randint(0, 5, size=n)
+    for i in range(n):
+        if kind[i] == 0:    # needle: third vertex almost on the first edge
+            a = rs.uniform(0, 1)
+            t[i, 2] = t[i, 0] + a * (t[i, 1] - t[i, 0]) + rs.uniform(-1e-6, 1e-6, 3)
+        elif kind[i] == 1:  # tiny
+            t[i, 1:] = t[i, 0] + rs.uniform(-1e-4, 1e-4, (2, 3))
+        elif kind[i] == 2:  # huge
+            t[i, 1:] = t[i, 0] + rs.uniform(-50, 50, (2, 3))
+        elif kind[i] == 3:  # exactly degenerate
+            t[i, 2] = t[i, 0]
+    return t.astype(f32)
+
+
+def rays_through_features(rs, tris, origins, per_tri=6):
+    """Directions aimed at points on (and a hair beside) triangle edges and vertices."""
+    n = tris.shape[0]
+    dirs, orgs = [], []
+    for j in range(per_tri):
+        w = rs.dirichlet([1, 1, 1], size=n)
+        mode = j % 3
+        if mode == 0:
+            w[:, rs.randint(0, 3)] = 0.0         # on an edge
+        elif mode == 1:
+            w[:] = 0.0
+            w[np.arange(n), rs.randint(0, 3, n)] = 1.0  # at a vertex
+        w /= w.sum(1, keepdims=True)
+        p = (w[:, :, None] * tris.astype(np.float64)).sum(1)
+        p += rs.uniform(-1, 1, p.shape) * 10.0 ** rs.uniform(-9, -5, (n, 1))
+        o = origins[rs.randint(0, origins.shape[0], n)]
+        d = p - o
+        d /= np.linalg.norm(d, axis=1, keepdims=True) + 1e-300
+        dirs.append(d)
+        orgs.append(o)
+    return np.concatenate(orgs).astype(f32), np.concatenate(dirs).astype(f32)
+
+
+def run_general(fm, tris, org, dirs):
+    c, r = bounding_sphere(tris)
+    stats = (C.c_longlong * 4)()
+    tris = np.ascontiguousarray(tris, dtype=f32)
+    org = np.ascontiguousarray(org, dtype=f32)
+    dirs = np.ascontiguousarray(dirs, dtype=f32)
+    fm.fm_check_general(tris.shape[0], tris.ctypes.data, org.shape[0], org.ctypes.data, dirs.ctypes.data,
+                        c.ctypes.data, r, stats)
+    return list(stats)
+
+
+def run_origin(fm, tris, O, org, dirs):
+    c, r = bounding_sphere(tris)
+    stats = (C.c_longlong * 4)()
+    tris = np.ascontiguousarray(tris, dtype=f32)
+    O = np.ascontiguousarray(O, dtype=f32)
+    org = np.ascontiguousarray(org, dtype=f32)
+    dirs = np.ascontiguousarray(dirs, dtype=f32)
+    fm.fm_check_origin(tris.shape[0], tris.ctypes.data, org.shape[0], O.ctypes.data, org.ctypes.data,
+                       dirs.ctypes.data, c.ctypes.data, r, stats)
+    return list(stats)
+
+
+SCENES = [
+    dict(name="soup", extent=1.0, size=0.05, offset=(0, 0, 0)),
+    dict(name="big_tris", extent=1.0, size=1.5, offset=(0, 0, 0)),
+    dict(name="far_from_world_origin", extent=1.0, size=0.05, offset=(900.0, -400.0, 250.0)),
+    dict(name="tiny_scene", extent=1e-3, size=1e-4, offset=(0, 0, 0)),
+    dict(name="large_scene", extent=1e4, size=300.0, offset=(0, 0, 0)),
+]
+
+
+@pytest.mark.parametrize("sc", SCENES, ids=[s["name"] for s in SCENES])
+def test_general_form_is_conservative(fm, sc):
+    rs = np.random.RandomState(11)
+    tris = tris_random(rs, 1500, sc["extent"], sc["size"], sc["offset"])
+    origins = (rs.uniform(-3, 3, (64, 3)) * sc["extent"] + np.asarray(sc["offset"]))
+    org, dirs = rays_through_features(rs, tris, origins)
+    # as intersect does: origin + dir*0.001 (float32)
+    org = (org + dirs * f32(0.001)).astype(f32)
+    pairs, passed, acc, bad = run_general(fm, tris, org, dirs)
+    assert bad == 0
+    assert acc > 1000               # the feature-aimed rays do exercise accepted pairs
+    assert passed < 0.2 * pairs     # and the filter does reject most pairs
+
+
+def test_general_form_nasty_triangles(fm):
+    rs = np.random.RandomState(5)
+    tris = tris_nasty(rs, 3000, 2.0)
+    origins = rs.uniform(-6, 6, (64, 3))
+    org, dirs = rays_through_features(rs, tris, origins)
+    org = (org + dirs * f32(0.001)).astype(f32)
+    pairs, passed, acc, bad = run_general(fm, tris, org, dirs)
+    assert bad == 0 and acc > 1000
+
+
+def test_general_form_rays_starting_on_triangles(fm):
+    """bounce rays: origins on a surface, directions random and grazing"""
+    rs = np.random.RandomState(6)
+    tris = tris_random(rs, 2000, 1.0, 0.2)
+    w = rs.dirichlet([1, 1, 1], size=2000)
+    p = (w[:, :, None] * tris.astype(np.float64)).sum(1)
+    d = rs.normal(size=(2000, 3))
+    # half of them nearly in the plane of their triangle
+    nrm = np.cross(tris[:, 1] - tris[:, 0], tris[:, 2] - tris[:, 0]).astype(np.float64)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    d[::2] -= (d[::2] * nrm[::2]).sum(1, keepdims=True) * nrm[::2] * (1 - 1e-4)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    org = (p.astype(f32) + d.astype(f32) * f32(0.001)).astype(f32)
+    pairs, passed, acc, bad = run_general(fm, tris, org, d.astype(f32))
+    assert bad == 0 and acc > 1000
+
+
+@pytest.mark.parametrize("sc", SCENES, ids=[s["name"] for s in SCENES])
+def test_shared_origin_primary_rays(fm, sc):
+    """raygen rays: one origin O, reference origin = O + dir*0.001"""
+    rs = np.random.RandomState(21)
+    tris = tris_random(rs, 1500, sc["extent"], sc["size"], sc["offset"])
+    for trial in range(3):
+        O = (rs.uniform(-3, 3, 3) * sc["extent"] + np.asarray(sc["offset"])).astype(f32)
+        _, dirs = rays_through_features(rs, tris, O[None, :].astype(np.float64))
+        org = (O[None, :] + dirs * f32(0.001)).astype(f32)
+        pairs, passed, acc, bad = run_origin(fm, tris, O, org, dirs)
+        assert bad == 0
+        assert acc > 1000 and passed < 0.2 * pairs
+
+
+@pytest.mark.parametrize("sc", SCENES[:3], ids=[s["name"] for s in SCENES[:3]])
+def test_shared_origin_shadow_rays(fm, sc):
+    """shadow rays as color builds them: from surface points p toward the light L with
+    lightDir = normalize(L - p), origin p + lightDir*1e-7 (raycol_cs.glsl:39-41)"""
+    rs = np.random.RandomState(31)
+    tris = tris_random(rs, 1500, sc["extent"], sc["size"], sc["offset"])
+    L = (rs.uniform(-3, 3, 3) * sc["extent"] + np.asarray(sc["offset"])).astype(f32)
+    # choose p so that the segment p -> L grazes triangle features: aim from L through a
+    # feature point and continue to a random distance behind it
+    _, dirs = rays_through_features(rs, tris, L[None, :].astype(np.float64))
+    dist = rs.uniform(0.5, 5.0, (dirs.shape[0], 1)) * sc["extent"]
+    p = (L[None, :].astype(np.float64) + dirs.astype(np.float64) * dist).astype(f32)
+    dlt = (L[None, :] - p).astype(f32)
+    inv = (f32(1.0) / np.sqrt((dlt * dlt).sum(1, dtype=f32))).astype(f32)
+    ld = (dlt * inv[:, None]).astype(f32)
+    org = (p + ld * f32(0.0000001)).astype(f32)
+    pairs, passed, acc, bad = run_origin(fm, tris, L, org, ld)
+    assert bad == 0
+    assert acc > 1000 and passed < 0.2 * pairs
+
+
+def test_degenerate_and_nonfinite_inputs_never_pass_wrongly(fm):
+    rs = np.random.RandomState(41)
+    tris = tris_random(rs, 64, 1.0, 0.3)
+    tris[0, 1] = tris[0, 0]                 # zero edge
+    tris[1, 2, 0] = np.nan                  # NaN vertex
+    tris[2, 1, 1] = np.inf                  # infinite vertex
+    org = rs.uniform(-3, 3, (256, 3)).astype(f32)
+    dirs = rs.normal(size=(256, 3)).astype(f32)
+    dirs[0] = 0.0                           # zero direction
+    dirs[1, 0] = np.nan
+    org[2, 1] = np.inf
+    org[3] = np.nan
+    pairs, passed, acc, bad = run_general(fm, tris, org, dirs)
+    assert bad == 0
+    O = f32([0.1, 0.2, -3.0])
+    pairs, passed, acc, bad = run_origin(fm, tris, O, (O[None, :] + dirs * f32(0.001)).astype(f32), dirs)
+    assert bad == 0
