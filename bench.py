@@ -70,11 +70,11 @@ def setup_scene(obj, wl):
 
 def cpu_baseline(wl, seconds_hint=15.0):
     """The oracle (a port of the reference's shaders) on the host cores, on a bounded sample:
-    the same scene and camera at 1/10 of the width and height (1/100 of the rays)."""
+    the same scene and camera at 1/20 of the width and height (1/400 of the rays)."""
     from oracle.rt_oracle import Oracle
     threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
     threads = max(1, min(threads, 64))
-    w, h = max(1, wl["width"] // 10), max(1, wl["height"] // 10)
+    w, h = max(1, wl["width"] // 20), max(1, wl["height"] // 20)
     o = Oracle(w, h, threads=threads)
     setup_scene(o, wl)
     rays = 0
@@ -93,7 +93,7 @@ def cpu_baseline(wl, seconds_hint=15.0):
             break
     dt = time.perf_counter() - t0
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": f"same scene, {n_views} view(s) at {w}x{h} (1/100 of the rays per view), "
+            "sample": f"same scene, {n_views} view(s) at {w}x{h} (1/400 of the rays per view), "
                       f"{wl['passes']} passes, oracle with {threads} OpenMP threads, {dt:.1f} s"}
 
 

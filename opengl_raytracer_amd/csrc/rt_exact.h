@@ -2,8 +2,8 @@
 //
 // Every expression is associated as the GLSL text associates it and evaluated in
 // IEEE binary32 with separately rounded multiplies and adds (the translation unit
-// is built with -ffp-contract=off; hipcc's default divide and sqrt are correctly
-// rounded).  Built-ins whose precision GLSL leaves to the implementation are
+// is built with -ffp-contract=off; hipcc expands `/` and __builtin_sqrtf to correctly
+// rounded sequences -- __fsqrt_rn does NOT: it is a bare v_sqrt_f32, 1 ulp).  Built-ins whose precision GLSL leaves to the implementation are
 // fixed as:  normalize(v) = v * (1 / sqrt(v.v));  distance = sqrt of the dot of
 // the difference;  reflect(I,N) = I - (2 (N.I)) N;  pow(x,30) by repeated
 // squaring;  max(x,0) = x < 0 ? 0 : x.
@@ -26,11 +26,11 @@ __device__ __forceinline__ v3 cross(v3 a, v3 b)
 {
     return V(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y);
 }
-__device__ __forceinline__ v3 normalize(v3 a) { return muls(a, 1.0f / __fsqrt_rn(dot(a, a))); }
+__device__ __forceinline__ v3 normalize(v3 a) { return muls(a, 1.0f / __builtin_sqrtf(dot(a, a))); }
 __device__ __forceinline__ float distance3(v3 a, v3 b)
 {
     v3 d = sub(a, b);
-    return __fsqrt_rn(dot(d, d));
+    return __builtin_sqrtf(dot(d, d));
 }
 __device__ __forceinline__ float max0(float x) { return (x < 0.0f) ? 0.0f : x; }
 __device__ __forceinline__ float pow30(float x)
@@ -69,7 +69,7 @@ __device__ __forceinline__ bool ray_sphere(v3 o, v3 d, v3 c, float r, float &t)
     if (s < 0.0f && outside) return false;
     float m_sqr = l_sqr - s * s;
     if (m_sqr > r_sqr) return false;
-    float q = __fsqrt_rn(r_sqr - m_sqr);
+    float q = __builtin_sqrtf(r_sqr - m_sqr);
     t = outside ? (s - q) : (s + q);
     return true;
 }

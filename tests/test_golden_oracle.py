@@ -42,7 +42,8 @@ def exact_check(tag, got, want):
         bad = rays_equal_bits(got, want)
         assert not bad.any(), tag + ": " + describe_mismatch(got, want, bad)
     elif tag == "depth":
-        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), tag
+        same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+        assert same.all(), tag
     else:
         assert np.array_equal(got, want), tag
 

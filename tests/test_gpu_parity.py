@@ -69,7 +69,8 @@ def test_stage_by_stage_against_oracle(rt, oracle_mod, kind, w, h, passes, nl):
             g.color(); c.color()
             assert_same(f"color {p}", g, c)
             assert_same_pixels(f"color {p}", g, c)
-        assert np.array_equal(g.read_depth().view(np.uint32), c.read_depth().view(np.uint32))
+        dg, dc = g.read_depth(), c.read_depth()
+        assert ((dg.view(np.uint32) == dc.view(np.uint32)) | (np.isnan(dg) & np.isnan(dc))).all()
 
 
 def test_default_reference_pose_and_lights(rt, oracle_mod):
@@ -87,7 +88,7 @@ def test_default_reference_pose_and_lights(rt, oracle_mod):
             o.render(2)
         assert_same("render", g, c)
         assert_same_pixels("render", g, c)
-        assert (g.read_rays()["primitiveID"] >= 0).sum() > 100
+        assert (g.read_pixels().reshape(-1, 4) != [26, 26, 26, 255]).any(axis=1).sum() > 1000
 
 
 # -- edge cases -------------------------------------------------------------------------
@@ -100,11 +101,15 @@ def test_empty_mesh_spheres_only(rt, oracle_mod):
             o.set_texture(None)
             o.set_lights(scenes.default_lights(), 2)
             o.set_camera((0, 0, 0), (0, -0.33, 0.94), (0, 0.94, 0.33), (1, 0, 0))
-            o.render(2)
+            o.render(1)
         assert_same("spheres", g, c)
         assert_same_pixels("spheres", g, c)
         ids = g.read_rays()["primitiveID"]
         assert (ids == 0).any()  # sphere 0 has id numTris + 0 = 0
+        for o in (g, c):
+            o.render(3)
+        assert_same("spheres 3 passes", g, c)
+        assert_same_pixels("spheres 3 passes", g, c)
 
 
 def test_zero_lights_all_grey(rt, oracle_mod):
