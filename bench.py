@@ -161,7 +161,8 @@ def main():
     log = g.kernel_log()
     stage_ms = g.stage_ms()
     tot = torch.tensor([cnt["closest_rays"], cnt["shadow_rays"], cnt["closest_pairs"], cnt["shadow_pairs"],
-                        cnt["closest_candidates"], cnt["shadow_candidates"]], dtype=torch.float64, device=dev)
+                        cnt["closest_candidates"], cnt["shadow_candidates"], cnt["closest_slow_steps"],
+                        cnt["shadow_slow_steps"]], dtype=torch.float64, device=dev)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -210,7 +211,8 @@ def main():
                        "rays_per_step": rays / steps,
                        "closest_hit_rays_per_step": tot[0] / steps, "shadow_rays_per_step": tot[1] / steps,
                        "pairs_per_step": (tot[2] + tot[3]) / steps,
-                       "filter_pass_rate": (tot[4] + tot[5]) / max(tot[2] + tot[3], 1.0)},
+                       "filter_pass_rate": (tot[4] + tot[5]) / max(tot[2] + tot[3], 1.0),
+                       "slow_steps_per_step": {"closest": tot[6] / steps, "shadow": tot[7] / steps}},
             "pairs_per_s": (tot[2] + tot[3]) / dt,
             "stage_ms_per_step_rank0": {"raygen": stage_ms[0] / steps, "intersect": stage_ms[1] / steps,
                                         "color": stage_ms[2] / steps},

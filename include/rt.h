@@ -170,7 +170,8 @@ int rt_stage_ms(rt_ctx *ctx, float ms[3]);
  *   [3] (ray, triangle) pairs tested by shadow traversal (after early exit)
  *   [4] pairs that passed the filter in closest-hit traversal
  *   [5] pairs that passed the filter in shadow traversal
- *   [6],[7] reserved */
+ *   [6] (wavefront, triangle) steps of closest-hit traversal that left the fast path
+ *   [7] the same for shadow traversal */
 int rt_get_counters(rt_ctx *ctx, uint64_t counters[8]);
 
 /* One record per traversal-kernel launch made by rt_intersect / rt_color since

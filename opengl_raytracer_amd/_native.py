@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librt_hip.so")
+# RT_HIP_LIB selects another build of the same library (A/B timing of kernel variants)
+LIB_PATH = os.environ.get("RT_HIP_LIB") or os.path.join(_HERE, "librt_hip.so")
 
 # Record layouts of include/rt.h ("OpenGL Raytracer/Ray.h":9-24, main.cpp:29-35, 148-167)
 RAY_DTYPE = np.dtype([

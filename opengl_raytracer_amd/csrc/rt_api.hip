@@ -46,6 +46,8 @@ struct rt_ctx {
     rtf::TriRec *rec_general = nullptr;
     rtf::TriRec *rec_camera = nullptr;
     rtf::TriRec *rec_lights = nullptr; // RT_MAX_LIGHTS x rec_stride
+    rtf::ConeRec *cone_camera = nullptr;
+    rtf::ConeRec *cone_lights = nullptr; // RT_MAX_LIGHTS x rec_stride
     size_t rec_stride = 0;
     bool camera_recs_dirty = true;
     bool light_recs_dirty = true;
@@ -63,9 +65,13 @@ struct rt_ctx {
     bool rays_share_camera_origin = false;
     bool rays_valid = false;
 
-    int *list = nullptr;
-    int *count_d = nullptr; // [0] live/intersect list size, [1] shade list size
+    int *list = nullptr;    // compacted ray indices (live rays / rays with a finite origin)
+    int *alist[2] = {nullptr, nullptr}; // shadow rays still unoccluded (slots), ping-pong
+    int *count_d = nullptr; // [0] intersect list, [1] shade list, [2],[3] alist sizes
     int *count_h = nullptr; // pinned
+    float *work = nullptr;  // per-slot planes behind job / scratch
+    Job job{};
+    Scratch scratch{};
 
     uint32_t *fb_own = nullptr;
     uint32_t *fb = nullptr;
@@ -83,7 +89,7 @@ struct rt_ctx {
     std::vector<std::pair<int, int>> ev_used; // (stage, pool index)
     size_t ev_next = 0;
     // kernel log: a ring of event pairs around the traversal launches
-    static constexpr int KLOG = 256;
+    static constexpr int KLOG = 1024;
     EventPair klog_ev[KLOG] = {};
     rt_kernel_record klog_rec[KLOG] = {};
     size_t klog_count = 0; // launches logged since the last read
@@ -185,8 +191,27 @@ extern "C" int rt_create(rt_ctx **out, int hip_device, int width, int height)
     setup_planes(c);
     CRCHK(hipMalloc(&c->row_map_d, (size_t)height * sizeof(int)));
     CRCHK(hipMalloc(&c->list, c->cap * sizeof(int)));
-    CRCHK(hipMalloc(&c->count_d, 4 * sizeof(int)));
-    CRCHK(hipHostMalloc(&c->count_h, 4 * sizeof(int)));
+    CRCHK(hipMalloc(&c->alist[0], c->cap * sizeof(int)));
+    CRCHK(hipMalloc(&c->alist[1], c->cap * sizeof(int)));
+    {
+        // 7 + 4 job planes + 6 float scratch planes + lit + occ + best (two words per slot)
+        const size_t planes = 7 + 4 + 6 + 1 + 1 + 2;
+        CRCHK(hipMalloc(&c->work, planes * c->stride * sizeof(float)));
+        float *b = c->work;
+        const size_t st = c->stride;
+        c->job.ox = b + 0 * st; c->job.oy = b + 1 * st; c->job.oz = b + 2 * st;
+        c->job.dx = b + 3 * st; c->job.dy = b + 4 * st; c->job.dz = b + 5 * st;
+        c->job.tmax = b + 6 * st;
+        c->scratch.sox = b + 7 * st; c->scratch.soy = b + 8 * st; c->scratch.soz = b + 9 * st;
+        c->scratch.lr = b + 10 * st; c->scratch.lg = b + 11 * st; c->scratch.lb = b + 12 * st;
+        c->scratch.lit = reinterpret_cast<int *>(b + 13 * st);
+        c->scratch.occ = reinterpret_cast<int *>(b + 14 * st);
+        c->scratch.best = reinterpret_cast<unsigned long long *>(b + 15 * st);
+        c->job.bx = b + 17 * st; c->job.by = b + 18 * st; c->job.bz = b + 19 * st;
+        c->job.g = b + 20 * st;
+    }
+    CRCHK(hipMalloc(&c->count_d, 8 * sizeof(int)));
+    CRCHK(hipHostMalloc(&c->count_h, 8 * sizeof(int)));
     CRCHK(hipMalloc(&c->fb_own, c->cap * sizeof(uint32_t)));
     CRCHK(hipMemsetAsync(c->fb_own, 0, c->cap * sizeof(uint32_t), c->stream));
     c->fb = c->fb_own;
@@ -229,8 +254,13 @@ extern "C" void rt_destroy(rt_ctx *c)
     (void)hipFree(c->rec_general);
     (void)hipFree(c->rec_camera);
     (void)hipFree(c->rec_lights);
+    (void)hipFree(c->cone_camera);
+    (void)hipFree(c->cone_lights);
     (void)hipFree(c->tex);
     (void)hipFree(c->list);
+    (void)hipFree(c->alist[0]);
+    (void)hipFree(c->alist[1]);
+    (void)hipFree(c->work);
     (void)hipFree(c->count_d);
     if (c->count_h) (void)hipHostFree(c->count_h);
     (void)hipFree(c->fb_own);
@@ -251,6 +281,8 @@ extern "C" int rt_set_mesh(rt_ctx *c, const rt_vertex *vertices, int num_vertice
     (void)hipFree(c->rec_general); c->rec_general = nullptr;
     (void)hipFree(c->rec_camera); c->rec_camera = nullptr;
     (void)hipFree(c->rec_lights); c->rec_lights = nullptr;
+    (void)hipFree(c->cone_camera); c->cone_camera = nullptr;
+    (void)hipFree(c->cone_lights); c->cone_lights = nullptr;
     c->num_vertices = num_vertices;
     c->num_tris = num_vertices / 3;
     // record arrays are padded to whole tiles so that a tile copy never leaves the allocation
@@ -263,6 +295,8 @@ extern "C" int rt_set_mesh(rt_ctx *c, const rt_vertex *vertices, int num_vertice
     HIPCHK(c, hipMalloc(&c->rec_general, c->rec_stride * sizeof(rtf::TriRec)));
     HIPCHK(c, hipMalloc(&c->rec_camera, c->rec_stride * sizeof(rtf::TriRec)));
     HIPCHK(c, hipMalloc(&c->rec_lights, RT_MAX_LIGHTS * c->rec_stride * sizeof(rtf::TriRec)));
+    HIPCHK(c, hipMalloc(&c->cone_camera, c->rec_stride * sizeof(rtf::ConeRec)));
+    HIPCHK(c, hipMalloc(&c->cone_lights, RT_MAX_LIGHTS * c->rec_stride * sizeof(rtf::ConeRec)));
     if (c->num_tris)
         hipLaunchKernelGGL(prep_general_kernel, dim3(cdiv(c->num_tris, BLOCK)), dim3(BLOCK), 0, c->stream, c->verts,
                            c->num_tris, c->rec_general);
@@ -281,8 +315,22 @@ extern "C" int rt_set_mesh(rt_ctx *c, const rt_vertex *vertices, int num_vertice
         }
         first = false;
     }
+    // the two spheres of trace.glsl:159-162 belong to every scene: rays start on them too
+    static const double sph[2][4] = {{0.0, -0.7, 2.0, 0.5}, {-2.0, 0.0, 0.0, 0.2}};
+    for (int sidx = 0; sidx < 2; sidx++)
+        for (int a = 0; a < 3; a++) {
+            double l = sph[sidx][a] - sph[sidx][3], h = sph[sidx][a] + sph[sidx][3];
+            if (first || l < lo[a]) lo[a] = l;
+            if (first || h > hi[a]) hi[a] = h;
+            if (sidx == 0 && a == 2) first = false;
+        }
     double ctr[3] = {(lo[0] + hi[0]) / 2, (lo[1] + hi[1]) / 2, (lo[2] + hi[2]) / 2};
     double r2 = 0;
+    for (int sidx = 0; sidx < 2; sidx++) {
+        double dx = sph[sidx][0] - ctr[0], dy = sph[sidx][1] - ctr[1], dz = sph[sidx][2] - ctr[2];
+        double d = std::sqrt(dx * dx + dy * dy + dz * dz) + sph[sidx][3];
+        if (d * d > r2) r2 = d * d;
+    }
     for (int i = 0; i < num_vertices; i++) {
         double dx = vertices[i].pos[0] - ctr[0], dy = vertices[i].pos[1] - ctr[1], dz = vertices[i].pos[2] - ctr[2];
         double d2 = dx * dx + dy * dy + dz * dz;
@@ -455,12 +503,24 @@ extern "C" int rt_raygen(rt_ctx *c)
     return RT_OK;
 }
 
-// picks the rays-per-lane variant for a launch over n rays
+// ---- launch geometry ---------------------------------------------------------
+// rays per lane: more rays amortise each LDS record read over more arithmetic;
+// fewer rays give small launches enough lanes to spread over 256 CUs.
 static int pick_rays_per_lane(int n)
 {
-    if (n >= 4 * BLOCK * 4 * 256) return 4;
-    if (n >= 2 * BLOCK * 2 * 256) return 2;
+    if (n >= 65536) return 4;
+    if (n >= 16384) return 2;
     return 1;
+}
+
+// splits `tiles` LDS tiles over blockIdx.y so that the launch has at least ~2048
+// workgroups (8 per CU): short launches then fill the chip and end together.
+static int pick_tiles_per_y(int ray_blocks, int tiles)
+{
+    int want_y = (2048 + ray_blocks - 1) / ray_blocks;
+    if (want_y < 1) want_y = 1;
+    if (want_y > tiles) want_y = tiles;
+    return (tiles + want_y - 1) / want_y;
 }
 
 static int klog_begin(rt_ctx *c, int stage, int form, int k, bool exact, unsigned long long rays,
@@ -480,28 +540,52 @@ static int klog_end(rt_ctx *c, size_t slot)
     return RT_OK;
 }
 
-template <int FORM, bool EXACT>
-static void launch_closest(rt_ctx *c, const TraceParams &p, int n_upper)
+template <int K, int FORM, bool ANYHIT>
+static void launch_traverse_k(rt_ctx *c, const TraverseParams &p, dim3 grid)
 {
-    // rays per lane: more rays amortise each LDS record read over more arithmetic;
-    // fewer rays give small launches enough workgroups to cover 256 CUs.
-    const int k = pick_rays_per_lane(n_upper);
-    if (k == 4)
-        hipLaunchKernelGGL((closest_hit_kernel<4, FORM, EXACT>), dim3(cdiv(n_upper, BLOCK * 4)), dim3(BLOCK), 0,
-                           c->stream, p);
-    else if (k == 2)
-        hipLaunchKernelGGL((closest_hit_kernel<2, FORM, EXACT>), dim3(cdiv(n_upper, BLOCK * 2)), dim3(BLOCK), 0,
-                           c->stream, p);
+    if (c->trace_mode == RT_TRACE_EXACT)
+        hipLaunchKernelGGL((traverse_kernel<K, FORM, ANYHIT, true>), grid, dim3(BLOCK), 0, c->stream, p);
     else
-        hipLaunchKernelGGL((closest_hit_kernel<1, FORM, EXACT>), dim3(cdiv(n_upper, BLOCK)), dim3(BLOCK), 0,
-                           c->stream, p);
+        hipLaunchKernelGGL((traverse_kernel<K, FORM, ANYHIT, false>), grid, dim3(BLOCK), 0, c->stream, p);
+}
+
+// One traversal launch: the rays of a list (at most n_upper of them) against the
+// triangles [tri_begin, tri_end).  stage: 1 closest hit, 2 shadow.
+static int launch_traverse(rt_ctx *c, TraverseParams p, int n_upper, int form, bool anyhit, int stage)
+{
+    const int k = pick_rays_per_lane(n_upper);
+    const int ray_blocks = cdiv(n_upper, BLOCK * k);
+    const int tiles = cdiv(p.tri_end - p.tri_begin, TILE);
+    if (ray_blocks <= 0 || tiles <= 0) return RT_OK;
+    p.tiles_per_y = pick_tiles_per_y(ray_blocks, tiles);
+    // sub-ranges start on multiples of the larger (cone) tile
+    p.tiles_per_y = (p.tiles_per_y + CONE_TILE / TILE - 1) / (CONE_TILE / TILE) * (CONE_TILE / TILE);
+    const dim3 grid(ray_blocks, cdiv(tiles, p.tiles_per_y));
+    size_t ks;
+    if (int r = klog_begin(c, stage, form, k, c->trace_mode == RT_TRACE_EXACT, (unsigned long long)n_upper,
+                           (unsigned long long)n_upper * (unsigned long long)(p.tri_end - p.tri_begin), &ks))
+        return r;
+#define RT_DISPATCH(KK)                                                             \
+    do {                                                                            \
+        if (form == 0 && !anyhit) launch_traverse_k<KK, 0, false>(c, p, grid);      \
+        else if (form == 1 && !anyhit) launch_traverse_k<KK, 1, false>(c, p, grid); \
+        else launch_traverse_k<KK, 1, true>(c, p, grid);                            \
+    } while (0)
+    if (k == 4) RT_DISPATCH(4);
+    else if (k == 2) RT_DISPATCH(2);
+    else RT_DISPATCH(1);
+#undef RT_DISPATCH
+    HIPCHK(c, hipGetLastError());
+    return klog_end(c, ks);
 }
 
 static int refresh_camera_recs(rt_ctx *c)
 {
     if (c->camera_recs_dirty && c->num_tris) {
         hipLaunchKernelGGL(prep_origin_kernel, dim3(cdiv(c->num_tris, BLOCK)), dim3(BLOCK), 0, c->stream, c->verts,
-                           c->num_tris, c->cam.pos[0], c->cam.pos[1], c->cam.pos[2], c->rec_camera);
+                           c->num_tris, c->cam.pos[0], c->cam.pos[1], c->cam.pos[2],
+                           rtf::scene_extent(c->cam.pos, c->center, c->radius),
+                           rtf::cone_reach_max(c->cam.pos, c->center, c->radius), c->rec_camera, c->cone_camera);
         HIPCHK(c, hipGetLastError());
     }
     c->camera_recs_dirty = false;
@@ -514,7 +598,10 @@ static int refresh_light_recs(rt_ctx *c)
         for (int a = 0; a < c->num_lights; a++) {
             hipLaunchKernelGGL(prep_origin_kernel, dim3(cdiv(c->num_tris, BLOCK)), dim3(BLOCK), 0, c->stream,
                                c->verts, c->num_tris, c->lights[a].pos[0], c->lights[a].pos[1], c->lights[a].pos[2],
-                               c->rec_lights + (size_t)a * c->rec_stride);
+                               rtf::scene_extent(c->lights[a].pos, c->center, c->radius),
+                               rtf::cone_reach_max(c->lights[a].pos, c->center, c->radius),
+                               c->rec_lights + (size_t)a * c->rec_stride,
+                               c->cone_lights + (size_t)a * c->rec_stride);
             HIPCHK(c, hipGetLastError());
         }
     }
@@ -531,6 +618,29 @@ static int read_count(rt_ctx *c, int which, int *out)
     return RT_OK;
 }
 
+static SharedOrigin shared_origin(rt_ctx *c, const float origin[3], float sign)
+{
+    SharedOrigin so{};
+    memcpy(so.origin, origin, sizeof so.origin);
+    memcpy(so.center, c->center, sizeof so.center);
+    so.radius = c->radius;
+    so.reach_max = (float)rtf::cone_reach_max(origin, c->center, c->radius);
+    so.sign = sign;
+    return so;
+}
+
+static void fill_traverse_common(rt_ctx *c, TraverseParams &p)
+{
+    p.job = c->job;
+    p.verts = c->verts;
+    p.num_tris = c->num_tris;
+    memcpy(p.center, c->center, sizeof p.center);
+    p.radius = c->radius;
+    p.best = c->scratch.best;
+    p.occ = c->scratch.occ;
+    p.counters = c->counters_d;
+}
+
 extern "C" int rt_intersect(rt_ctx *c)
 {
     if (!c) return RT_ERR_ARG;
@@ -539,50 +649,43 @@ extern "C" int rt_intersect(rt_ctx *c)
     if (int r = stage_begin(c, 1, &slot)) return r;
     if (c->n_rays > 0) {
         const bool shared = c->rays_share_camera_origin;
-        TraceParams p{};
-        p.rays = c->rays;
-        p.verts = c->verts;
-        p.num_tris = c->num_tris;
-        memcpy(p.center, c->center, sizeof p.center);
-        p.radius = c->radius;
-        memcpy(p.origin, c->cam.pos, sizeof p.origin);
-        memcpy(p.cam_pos, c->cam.pos, sizeof p.cam_pos);
-        p.depth = c->depth;
-        p.counters = c->counters_d;
+        const int *list = nullptr, *count = nullptr;
         int n_upper = c->n_rays;
         if (shared) {
             // fresh rays: all live, all through camera_pos
             if (int r = refresh_camera_recs(c)) return r;
-            p.list = nullptr;
-            p.count = nullptr;
-            p.n = c->n_rays;
-            p.recs = c->rec_camera;
         } else {
             HIPCHK(c, hipMemsetAsync(c->count_d, 0, sizeof(int), c->stream));
             hipLaunchKernelGGL((compact_kernel<0>), dim3(cdiv(c->n_rays, BLOCK * COMPACT_ITERS)), dim3(BLOCK), 0,
-                               c->stream, c->rays, c->n_rays, c->list, c->count_d, (uint32_t *)nullptr);
+                               c->stream, c->rays, (const int *)nullptr, (const int *)nullptr, c->n_rays,
+                               (const int *)nullptr, c->list, c->count_d, (uint32_t *)nullptr);
             HIPCHK(c, hipGetLastError());
             if (int r = read_count(c, 0, &n_upper)) return r;
-            p.list = c->list;
-            p.count = c->count_d;
-            p.n = 0;
-            p.recs = c->rec_general;
+            list = c->list;
+            count = c->count_d;
         }
         if (n_upper > 0) {
-            const bool exact = c->trace_mode == RT_TRACE_EXACT;
-            size_t ks;
-            if (int r = klog_begin(c, 1, shared ? 1 : 0, pick_rays_per_lane(n_upper), exact, n_upper,
-                                   (unsigned long long)n_upper * (unsigned long long)c->num_tris, &ks))
-                return r;
-            if (shared) {
-                if (exact) launch_closest<1, true>(c, p, n_upper);
-                else launch_closest<1, false>(c, p, n_upper);
-            } else {
-                if (exact) launch_closest<0, true>(c, p, n_upper);
-                else launch_closest<0, false>(c, p, n_upper);
-            }
+            hipLaunchKernelGGL(intersect_setup_kernel, dim3(cdiv(n_upper, BLOCK)), dim3(BLOCK), 0, c->stream, c->rays,
+                               list, count, n_upper, c->job, c->scratch.best, shared ? 1 : 0,
+                               shared_origin(c, c->cam.pos, 1.0f));
             HIPCHK(c, hipGetLastError());
-            if (int r = klog_end(c, ks)) return r;
+            TraverseParams p{};
+            fill_traverse_common(c, p);
+            p.alist = nullptr;
+            p.count = count;
+            p.n = n_upper;
+            p.recs = shared ? c->rec_camera : c->rec_general;
+            p.cones = c->cone_camera;
+            p.reach_max = (float)rtf::cone_reach_max(c->cam.pos, c->center, c->radius);
+            p.dir_sign = 1.0f;
+            memcpy(p.origin, c->cam.pos, sizeof p.origin);
+            p.tri_begin = 0;
+            p.tri_end = c->num_tris;
+            if (int r = launch_traverse(c, p, n_upper, shared ? 1 : 0, false, 1)) return r;
+            hipLaunchKernelGGL(intersect_finish_kernel, dim3(cdiv(n_upper, BLOCK)), dim3(BLOCK), 0, c->stream,
+                               c->rays, list, count, n_upper, c->job, c->scratch.best, c->verts, c->num_tris, c->cam,
+                               c->depth, c->counters_d);
+            HIPCHK(c, hipGetLastError());
         }
     }
     if (int r = stage_end(c, slot)) return r;
@@ -590,16 +693,12 @@ extern "C" int rt_intersect(rt_ctx *c)
     return RT_OK;
 }
 
-template <bool EXACT>
-static void launch_shade(rt_ctx *c, const ShadeParams &p, int n_upper)
+// triangles per shadow chunk: rays found occluded in one chunk are dropped before the next
+static int shadow_chunk_tris(int num_tris)
 {
-    const int k = pick_rays_per_lane(n_upper);
-    if (k == 4)
-        hipLaunchKernelGGL((shade_kernel<4, EXACT>), dim3(cdiv(n_upper, BLOCK * 4)), dim3(BLOCK), 0, c->stream, p);
-    else if (k == 2)
-        hipLaunchKernelGGL((shade_kernel<2, EXACT>), dim3(cdiv(n_upper, BLOCK * 2)), dim3(BLOCK), 0, c->stream, p);
-    else
-        hipLaunchKernelGGL((shade_kernel<1, EXACT>), dim3(cdiv(n_upper, BLOCK)), dim3(BLOCK), 0, c->stream, p);
+    int chunk = (num_tris + 7) / 8;
+    if (chunk < 4096) chunk = 4096;
+    return (chunk + CONE_TILE - 1) / CONE_TILE * CONE_TILE;
 }
 
 extern "C" int rt_color(rt_ctx *c)
@@ -618,41 +717,62 @@ extern "C" int rt_color(rt_ctx *c)
             if (int r = refresh_light_recs(c)) return r;
             HIPCHK(c, hipMemsetAsync(c->count_d + 1, 0, sizeof(int), c->stream));
             hipLaunchKernelGGL((compact_kernel<1>), dim3(cdiv(c->n_rays, BLOCK * COMPACT_ITERS)), dim3(BLOCK), 0,
-                               c->stream, c->rays, c->n_rays, c->list, c->count_d + 1, c->fb);
+                               c->stream, c->rays, (const int *)nullptr, (const int *)nullptr, c->n_rays,
+                               (const int *)nullptr, c->list, c->count_d + 1, c->fb);
             HIPCHK(c, hipGetLastError());
-            int n_upper = 0;
-            if (int r = read_count(c, 1, &n_upper)) return r;
-            if (n_upper > 0) {
-                ShadeParams p{};
-                p.rays = c->rays;
-                p.list = c->list;
-                p.count = c->count_d + 1;
-                p.light_recs = c->rec_lights;
-                p.rec_stride = c->rec_stride;
-                p.verts = c->verts;
-                p.num_vertices = c->num_vertices;
-                p.num_tris = c->num_tris;
-                memcpy(p.center, c->center, sizeof p.center);
-                p.radius = c->radius;
-                memcpy(p.cam_pos, c->cam.pos, sizeof p.cam_pos);
-                p.num_lights = c->num_lights;
-                memcpy(p.lights, c->lights, sizeof(rt_light) * RT_MAX_LIGHTS);
-                p.tex = c->tex;
-                p.tex_w = c->tex_w;
-                p.tex_h = c->tex_h;
-                p.fb = c->fb;
-                p.counters = c->counters_d;
-                const bool exact = c->trace_mode == RT_TRACE_EXACT;
-                size_t ks;
-                if (int r = klog_begin(c, 2, 1, pick_rays_per_lane(n_upper), exact, n_upper,
-                                       (unsigned long long)n_upper * (unsigned long long)c->num_tris *
-                                           (unsigned long long)c->num_lights,
-                                       &ks))
-                    return r;
-                if (exact) launch_shade<true>(c, p, n_upper);
-                else launch_shade<false>(c, p, n_upper);
+            int n0 = 0;
+            if (int r = read_count(c, 1, &n0)) return r;
+            if (n0 > 0) {
+                const int *cnt0 = c->count_d + 1;
+                const dim3 g0(cdiv(n0, BLOCK));
+                hipLaunchKernelGGL(color_begin_kernel, g0, dim3(BLOCK), 0, c->stream, c->rays, c->list, cnt0,
+                                   c->scratch);
                 HIPCHK(c, hipGetLastError());
-                if (int r = klog_end(c, ks)) return r;
+                const int chunk = shadow_chunk_tris(c->num_tris);
+                for (int a = 0; a < c->num_lights; a++) {
+                    hipLaunchKernelGGL(shadow_setup_kernel, g0, dim3(BLOCK), 0, c->stream, cnt0, c->scratch, c->job,
+                                       c->lights[a].pos[0], c->lights[a].pos[1], c->lights[a].pos[2],
+                                       shared_origin(c, c->lights[a].pos, -1.0f), c->counters_d);
+                    HIPCHK(c, hipGetLastError());
+                    const int *alist = nullptr; // nullptr: slots 0..n0-1
+                    const int *acount = cnt0;
+                    int pp = 0;
+                    for (int t0 = 0; t0 < c->num_tris; t0 += chunk) {
+                        TraverseParams p{};
+                        fill_traverse_common(c, p);
+                        p.alist = alist;
+                        p.count = acount;
+                        p.n = n0;
+                        p.recs = c->rec_lights + (size_t)a * c->rec_stride;
+                        p.cones = c->cone_lights + (size_t)a * c->rec_stride;
+                        p.reach_max = (float)rtf::cone_reach_max(c->lights[a].pos, c->center, c->radius);
+                        p.dir_sign = -1.0f;
+                        memcpy(p.origin, c->lights[a].pos, sizeof p.origin);
+                        p.tri_begin = t0;
+                        p.tri_end = (t0 + chunk < c->num_tris) ? t0 + chunk : c->num_tris;
+                        if (int r = launch_traverse(c, p, n0, 1, true, 2)) return r;
+                        if (p.tri_end < c->num_tris) {
+                            // keep the rays that are still unoccluded for the next chunk
+                            int *ocount = c->count_d + 2 + pp;
+                            HIPCHK(c, hipMemsetAsync(ocount, 0, sizeof(int), c->stream));
+                            hipLaunchKernelGGL((compact_kernel<2>), dim3(cdiv(n0, BLOCK * COMPACT_ITERS)),
+                                               dim3(BLOCK), 0, c->stream, c->rays, alist, acount, n0,
+                                               (const int *)c->scratch.occ, c->alist[pp], ocount, (uint32_t *)nullptr);
+                            HIPCHK(c, hipGetLastError());
+                            alist = c->alist[pp];
+                            acount = ocount;
+                            pp ^= 1;
+                        }
+                    }
+                    hipLaunchKernelGGL(shadow_finish_kernel, g0, dim3(BLOCK), 0, c->stream, c->rays,
+                                       (const int *)c->list, alist, acount, n0, c->scratch, c->job, c->lights[a],
+                                       c->cam);
+                    HIPCHK(c, hipGetLastError());
+                }
+                hipLaunchKernelGGL(color_finish_kernel, g0, dim3(BLOCK), 0, c->stream, c->rays, (const int *)c->list,
+                                   cnt0, c->scratch, c->verts, c->num_vertices, (const uint32_t *)c->tex, c->tex_w,
+                                   c->tex_h, c->fb);
+                HIPCHK(c, hipGetLastError());
             }
         }
     }

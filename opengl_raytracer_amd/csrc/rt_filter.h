@@ -161,9 +161,11 @@ RT_HD float min3f(float a, float b, float c) { return fminf(fminf(a, b), c); }
 RT_HD float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 
 // General form.  (ox,oy,oz) is the ray origin the reference would use, (hx,hy,hz)
-// the direction multiplied by dir_scale().  Returns g; the pair passes iff g >= -1.
-RT_HD float filter_general(const float *rec, float ox, float oy, float oz, float hx,
-                           float hy, float hz)
+// the direction multiplied by dir_scale().  Gives lo = min and hi = max of the three
+// scaled triple products; the pair passes iff lo >= -1 or hi <= 1, i.e. iff
+// max(lo, -hi) >= -1.
+RT_HD void filter_general_lohi(const float *rec, float ox, float oy, float oz, float hx,
+                               float hy, float hz, float &lo, float &hi)
 {
     float sx = ox - rec[0], sy = oy - rec[1], sz = oz - rec[2];
     // m = s x h
@@ -174,21 +176,194 @@ RT_HD float filter_general(const float *rec, float ox, float oy, float oz, float
     float Vn = fmaf(rec[5], mz, fmaf(rec[4], my, rec[3] * mx));  //  e1' . m  = -sc sv
     float A = fmaf(rec[11], hz, fmaf(rec[10], hy, rec[9] * hx)); //  h . N''  = -sc a
     float W = (-A - U) + Vn;                                     //  sc (a - su - sv)
-    float lo = min3f(U, -Vn, W);
-    float hi = max3f(U, -Vn, W);
+    lo = min3f(U, -Vn, W);
+    hi = max3f(U, -Vn, W);
+}
+
+RT_HD float filter_general(const float *rec, float ox, float oy, float oz, float hx,
+                           float hy, float hz)
+{
+    float lo, hi;
+    filter_general_lohi(rec, ox, oy, oz, hx, hy, hz, lo, hi);
     return fmaxf(lo, -hi);
 }
 
 // Shared-origin form: the record was built for origin O and the ray's line
 // passes through O.  (hx,hy,hz) as above.
-RT_HD float filter_origin(const float *rec, float hx, float hy, float hz)
+RT_HD void filter_origin_lohi(const float *rec, float hx, float hy, float hz, float &lo, float &hi)
 {
     float F0 = fmaf(rec[2], hz, fmaf(rec[1], hy, rec[0] * hx));
     float F1 = fmaf(rec[5], hz, fmaf(rec[4], hy, rec[3] * hx));
     float F2 = fmaf(rec[8], hz, fmaf(rec[7], hy, rec[6] * hx));
-    float lo = min3f(F0, F1, F2);
-    float hi = max3f(F0, F1, F2);
+    lo = min3f(F0, F1, F2);
+    hi = max3f(F0, F1, F2);
+}
+
+RT_HD float filter_origin(const float *rec, float hx, float hy, float hz)
+{
+    float lo, hi;
+    filter_origin_lohi(rec, hx, hy, hz, lo, hi);
     return fmaxf(lo, -hi);
+}
+
+
+// ---------------------------------------------------------------------------
+// Cone pre-filter for rays whose line passes through a shared origin O.
+//
+// Seen from O a triangle is a spherical triangle of directions.  The edge filter
+// above lets a direction through only if it lies inside that spherical triangle
+// grown by a small angle per edge (plus its mirror image, which belongs to hits
+// behind O).  A cone (unit axis, cosine threshold) that contains the grown
+// spherical triangle therefore rejects nothing the edge filter -- and hence the
+// reference -- could accept, and testing it costs one dot product per pair.
+//
+// make_cone_rec builds that cone in double precision from the ROUNDED edge record
+// (so it bounds exactly what the edge filter evaluates at run time):
+//   n_k   = +-c_k/|c_k|, signed so that the opposite vertex is inside,
+//   b_k   = -(2^-15 reach_max 1.001 + 2^-22 |c_k|)/|c_k|   the edge filter's threshold
+//           for any ray whose own reach is <= reach_max,
+//   corner(k,l) = the unit direction with d.n_k = b_k and d.n_l = b_l next to the
+//           shared vertex; the grown triangle is the hull of the three corners up to
+//           an outward bulge <= max asin(-b_k),
+//   threshold = cos(max angle(axis, corner) + 2 max asin(-b_k) + 2^-18) - 2^-19
+//           (the last term covers the float dot product and the normalised direction).
+// Whenever that construction is not safe -- a vertex at O, O within 2^-16 S of the
+// triangle's plane (then rounding decides on which side of O the reference sees the
+// hit), a corner that does not exist, an opening angle beyond 1.4 rad -- the record is
+// (0,0,0,-2): every direction passes and the edge filter decides.
+// Degenerate triangles (all-NaN edge record) get (0,0,0,2): nothing passes.
+// ---------------------------------------------------------------------------
+struct ConeRec {
+    float v[4];
+};
+
+RT_HD void cone_always(ConeRec *c) { c->v[0] = c->v[1] = c->v[2] = 0.0f; c->v[3] = -2.0f; }
+RT_HD void cone_never(ConeRec *c) { c->v[0] = c->v[1] = c->v[2] = 0.0f; c->v[3] = 2.0f; }
+
+RT_HD double dot3d(const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+RT_HD void cross3d(const double *a, const double *b, double *o)
+{
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+RT_HD void make_cone_rec(const float X[3], const float Y[3], const float Z[3], const float O[3],
+                         const TriRec *edge, double scene_extent, double reach_max, ConeRec *out)
+{
+    if (!(edge->v[0] == edge->v[0])) { // NaN record: degenerate triangle
+        cone_never(out);
+        return;
+    }
+    double p[3][3];
+    for (int i = 0; i < 3; i++) {
+        p[0][i] = (double)X[i] - (double)O[i];
+        p[1][i] = (double)Y[i] - (double)O[i];
+        p[2][i] = (double)Z[i] - (double)O[i];
+    }
+    double u[3][3];
+    for (int v = 0; v < 3; v++) {
+        double l = sqrt(dot3d(p[v], p[v]));
+        if (!(l > 0.0) || !(l < 1e300)) { cone_always(out); return; }
+        for (int i = 0; i < 3; i++) u[v][i] = p[v][i] / l;
+    }
+    // distance of O from the triangle's plane
+    double e1[3], e2[3], N[3];
+    for (int i = 0; i < 3; i++) { e1[i] = p[1][i] - p[0][i]; e2[i] = p[2][i] - p[0][i]; }
+    cross3d(e1, e2, N);
+    double nl = sqrt(dot3d(N, N));
+    if (!(nl > 0.0)) { cone_always(out); return; }
+    double h = fabs(dot3d(p[0], N)) / nl;
+    if (!(h > scene_extent * 1.52587890625e-05)) { cone_always(out); return; } // 2^-16
+
+    // edge k of the record: c0 ~ p1 x p2 (opposite vertex 0), c1 ~ p2 x p0, c2 ~ p0 x p1
+    double n[3][3], b[3], beta_max = 0.0;
+    for (int k = 0; k < 3; k++) {
+        double c[3] = {(double)edge->v[3 * k], (double)edge->v[3 * k + 1], (double)edge->v[3 * k + 2]};
+        double cl = sqrt(dot3d(c, c));
+        if (!(cl > 0.0)) { cone_always(out); return; }
+        double sgn = dot3d(c, u[k]);
+        if (sgn == 0.0) { cone_always(out); return; }
+        sgn = sgn > 0.0 ? 1.0 : -1.0;
+        for (int i = 0; i < 3; i++) n[k][i] = sgn * c[i] / cl;
+        double delta = 3.0517578125e-05 * reach_max * 1.001 + 2.384185791015625e-07 * cl; // 2^-15, 2^-22
+        b[k] = -delta / cl;
+        if (!(b[k] > -0.5)) { cone_always(out); return; }
+        double beta = asin(-b[k]);
+        if (beta > beta_max) beta_max = beta;
+    }
+    // axis: towards the middle of the three vertex directions, rounded to float first
+    double ax[3] = {u[0][0] + u[1][0] + u[2][0], u[0][1] + u[1][1] + u[2][1], u[0][2] + u[1][2] + u[2][2]};
+    double al = sqrt(dot3d(ax, ax));
+    if (!(al > 1e-3)) { cone_always(out); return; }
+    float axf[3] = {(float)(ax[0] / al), (float)(ax[1] / al), (float)(ax[2] / al)};
+    double a[3] = {(double)axf[0], (double)axf[1], (double)axf[2]};
+    double an = sqrt(dot3d(a, a));
+    double cos_min = 1.0;
+    for (int v = 0; v < 3; v++) { // corner next to vertex v: edges k != v
+        int k = (v + 1) % 3, l = (v + 2) % 3;
+        double g = dot3d(n[k], n[l]);
+        double det = 1.0 - g * g;
+        if (!(det > 1e-12)) { cone_always(out); return; }
+        double x = (b[k] - g * b[l]) / det, y = (b[l] - g * b[k]) / det;
+        double w = x * x + y * y + 2.0 * x * y * g;
+        if (!(w < 0.25)) { cone_always(out); return; }
+        double m[3];
+        cross3d(n[k], n[l], m);
+        double ml = sqrt(dot3d(m, m));
+        double z = sqrt(1.0 - w) / ml;
+        if (dot3d(m, u[v]) < 0.0) z = -z;
+        double cdir[3];
+        for (int i = 0; i < 3; i++) cdir[i] = x * n[k][i] + y * n[l][i] + z * m[i];
+        double cs = dot3d(cdir, a) / an; // cdir is unit by construction
+        if (cs < cos_min) cos_min = cs;
+        // the vertex direction itself must be inside the cone too
+        double cv = dot3d(u[v], a) / an;
+        if (cv < cos_min) cos_min = cv;
+    }
+    if (!(cos_min > -1.0)) { cone_always(out); return; }
+    double theta = acos(cos_min > 1.0 ? 1.0 : cos_min) + 2.0 * beta_max + 3.814697265625e-06; // 2^-18
+    if (!(theta < 1.4)) { cone_always(out); return; }
+    double thr = cos(theta) * an - 1.9073486328125e-06; // 2^-19; `an` undoes the rounding of the axis length
+    out->v[0] = axf[0]; out->v[1] = axf[1]; out->v[2] = axf[2];
+    float t = (float)thr;
+    if ((double)t > thr) t = nextafterf(t, -2.0f);
+    out->v[3] = t;
+}
+
+// `reach` of a ray whose line passes through the shared origin O (see dir_scale): the
+// geometric part bounds |o - X| + (longest edge) and |X - O| for every vertex X inside the
+// bounding sphere (C, R); the last term covers the only errors that grow with the absolute
+// size of the coordinates -- the rounding of the ray's own origin, <= eps |o| -- with a
+// margin of 8 relative to the 256 eps of the geometric part.
+RT_HD float reach_shared(const float O[3], const float o[3], const float C[3], float R)
+{
+    float a = sqrtf((O[0] - C[0]) * (O[0] - C[0]) + (O[1] - C[1]) * (O[1] - C[1]) + (O[2] - C[2]) * (O[2] - C[2]));
+    float b = sqrtf((o[0] - C[0]) * (o[0] - C[0]) + (o[1] - C[1]) * (o[1] - C[1]) + (o[2] - C[2]) * (o[2] - C[2]));
+    float c = sqrtf(O[0] * O[0] + O[1] * O[1] + O[2] * O[2]);
+    float d = sqrtf(o[0] * o[0] + o[1] * o[1] + o[2] * o[2]);
+    return a + b + 3.0f * R + 0.125f * (c + d);
+}
+
+// largest reach_shared() for which the cones built for origin O are valid: it covers rays
+// that start next to O (camera rays) and rays that start inside the bounding sphere (shadow rays)
+RT_HD double cone_reach_max(const float O[3], const float C[3], float R)
+{
+    double oc = sqrt(((double)O[0] - C[0]) * ((double)O[0] - C[0]) + ((double)O[1] - C[1]) * ((double)O[1] - C[1]) +
+                     ((double)O[2] - C[2]) * ((double)O[2] - C[2]));
+    double o = sqrt((double)O[0] * O[0] + (double)O[1] * O[1] + (double)O[2] * O[2]);
+    double c = sqrt((double)C[0] * C[0] + (double)C[1] * C[1] + (double)C[2] * C[2]);
+    return (2.0 * oc + 4.0 * (double)R + 0.125 * (2.0 * o + c + (double)R)) * 1.0001 + 0.02;
+}
+// scale of the rounding errors in the reference's t and light distance, for the rule "O is
+// too close to the triangle's plane to tell on which side of O the reference sees the hit"
+RT_HD double scene_extent(const float O[3], const float C[3], float R)
+{
+    double oc = sqrt(((double)O[0] - C[0]) * ((double)O[0] - C[0]) + ((double)O[1] - C[1]) * ((double)O[1] - C[1]) +
+                     ((double)O[2] - C[2]) * ((double)O[2] - C[2]));
+    double o = sqrt((double)O[0] * O[0] + (double)O[1] * O[1] + (double)O[2] * O[2]);
+    double c = sqrt((double)C[0] * C[0] + (double)C[1] * C[1] + (double)C[2] * C[2]);
+    return oc + (double)R + 0.125 * (o + c + (double)R);
 }
 
 } // namespace rtf

@@ -38,7 +38,7 @@ struct Camera {
 };
 
 // counters (see rt_get_counters)
-enum { C_CH_RAYS = 0, C_SH_RAYS, C_CH_PAIRS, C_SH_PAIRS, C_CH_CAND, C_SH_CAND };
+enum { C_CH_RAYS = 0, C_SH_RAYS, C_CH_PAIRS, C_SH_PAIRS, C_CH_CAND, C_SH_CAND, C_CH_SLOW, C_SH_SLOW };
 
 __device__ __forceinline__ void add_counter(unsigned long long *c, int which, unsigned long long v)
 {
@@ -149,8 +149,9 @@ __global__ __launch_bounds__(BLOCK) void prep_general_kernel(const rt_vertex *__
 }
 
 __global__ __launch_bounds__(BLOCK) void prep_origin_kernel(const rt_vertex *__restrict__ v, int num_tris,
-                                                            float ox, float oy, float oz,
-                                                            rtf::TriRec *__restrict__ out)
+                                                            float ox, float oy, float oz, double extent,
+                                                            double reach_max, rtf::TriRec *__restrict__ out,
+                                                            rtf::ConeRec *__restrict__ cones)
 {
     const int k = blockIdx.x * BLOCK + threadIdx.x;
     if (k >= num_tris) return;
@@ -158,38 +159,54 @@ __global__ __launch_bounds__(BLOCK) void prep_origin_kernel(const rt_vertex *__r
     rtf::TriRec r;
     rtf::make_origin_rec(v[3 * k].pos, v[3 * k + 1].pos, v[3 * k + 2].pos, O, &r);
     out[k] = r;
+    rtf::ConeRec c;
+    rtf::make_cone_rec(v[3 * k].pos, v[3 * k + 1].pos, v[3 * k + 2].pos, O, &r, extent, reach_max, &c);
+    cones[k] = c;
 }
 
 // ---------------------------------------------------------------------------
-// stream compaction: list[] = indices i in [0,n) with pred(i), block segments in
-// arbitrary order, index order inside a segment of 2048 rays.
-//   MODE 0: live rays            (primitiveID != -2)     -- before intersect
-//   MODE 1: rays with a finite origin                    -- before shading; the
-//           others are reference-grey (see shade kernel) and get their pixel here
+// stream compaction: out[] = the entries that satisfy a predicate; workgroup
+// segments land in arbitrary order, entries keep their order inside a segment of
+// 2048.
+//   MODE 0: ray indices i in [0,n) that are live      (primitiveID != -2)   -- before intersect
+//   MODE 1: ray indices with a finite origin                               -- before shading;
+//           the others are reference-grey (see color_finish_kernel) and get their pixel here
+//   MODE 2: slots of in_list (or 0..n-1 when in_list is null) whose shadow ray is not yet
+//           occluded (occ[slot] == 0)                                      -- between shadow chunks
 // ---------------------------------------------------------------------------
 constexpr int COMPACT_ITERS = 8;
 
 template <int MODE>
-__global__ __launch_bounds__(BLOCK) void compact_kernel(RaySoA r, int n, int *__restrict__ list,
-                                                        int *__restrict__ count, uint32_t *__restrict__ fb)
+__global__ __launch_bounds__(BLOCK) void compact_kernel(RaySoA r, const int *__restrict__ in_list,
+                                                        const int *__restrict__ in_count, int n_fixed,
+                                                        const int *__restrict__ occ, int *__restrict__ out,
+                                                        int *__restrict__ out_count, uint32_t *__restrict__ fb)
 {
     __shared__ int s_cnt[COMPACT_ITERS][BLOCK / 64];
     __shared__ int s_base;
+    const int n = in_count ? *in_count : n_fixed;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int chunk = blockIdx.x * (BLOCK * COMPACT_ITERS);
+    if (chunk >= n) return;
     unsigned long long masks[COMPACT_ITERS];
+    int value[COMPACT_ITERS];
 #pragma unroll
     for (int it = 0; it < COMPACT_ITERS; it++) {
         const int i = chunk + it * BLOCK + tid;
         bool p = false;
+        value[it] = i;
         if (i < n) {
             if (MODE == 0) {
                 p = r.id[i] != -2;
-            } else {
+            } else if (MODE == 1) {
                 float a = r.ox[i], b = r.oy[i], c = r.oz[i];
                 // finite <=> |x| < inf (false for NaN)
                 p = (fabsf(a) < INFINITY) && (fabsf(b) < INFINITY) && (fabsf(c) < INFINITY);
                 if (!p) fb[i] = 0xff1a1a1au; // vec3(0.1) -> 26, alpha 255
+            } else {
+                const int slot = in_list ? in_list[i] : i;
+                value[it] = slot;
+                p = occ[slot] == 0;
             }
         }
         masks[it] = __ballot(p);
@@ -204,7 +221,7 @@ __global__ __launch_bounds__(BLOCK) void compact_kernel(RaySoA r, int n, int *__
                 s_cnt[it][w] = tot;
                 tot += c;
             }
-        s_base = tot ? atomicAdd(count, tot) : 0;
+        s_base = tot ? atomicAdd(out_count, tot) : 0;
     }
     __syncthreads();
     const int base = s_base;
@@ -212,7 +229,7 @@ __global__ __launch_bounds__(BLOCK) void compact_kernel(RaySoA r, int n, int *__
 #pragma unroll
     for (int it = 0; it < COMPACT_ITERS; it++) {
         const unsigned long long m = masks[it];
-        if ((m >> lane) & 1ull) list[base + s_cnt[it][wave] + __popcll(m & lt)] = chunk + it * BLOCK + tid;
+        if ((m >> lane) & 1ull) out[base + s_cnt[it][wave] + __popcll(m & lt)] = value[it];
     }
 }
 
@@ -223,13 +240,121 @@ __global__ void fill_grey_kernel(uint32_t *__restrict__ fb, int n)
 }
 
 // ---------------------------------------------------------------------------
-// shared pieces of the two traversal kernels
+// per-slot work arrays.  A "slot" is a position in a compacted list, so these are
+// dense and every access is coalesced.
 // ---------------------------------------------------------------------------
+struct Job {            // the ray a traversal launch traces, exactly as the reference forms it
+    float *ox, *oy, *oz; // origin (already offset: + dir*0.001 for intersect, + lightDir*1e-7 for shadows)
+    float *dx, *dy, *dz; // direction
+    float *tmax;         // shadow rays: distance to the light (raycol_cs.glsl:47)
+    // shared-origin traversal only: what its two filter levels read, prepared once per ray
+    float *bx, *by, *bz; // unit direction, pointing from the shared origin towards the triangles
+    float *g;            // dir_scale() of that unit direction; negative when the ray is outside
+                         // the range the cones were built for (then only the edge filter applies)
+};
+
+// fills job.b* and job.g for a ray with origin o and direction d (sign: see TraverseParams::dir_sign)
+__device__ __forceinline__ void prepare_shared(const Job &job, int slot, v3 o, v3 d, const float *origin,
+                                               const float *center, float radius, float reach_max, float sign)
+{
+    const float oo[3] = {o.x, o.y, o.z};
+    const float reach = rtf::reach_shared(origin, oo, center, radius);
+    const float inv = sign / sqrtf(rtx::dot(d, d));
+    const float bx = d.x * inv, by = d.y * inv, bz = d.z * inv;
+    const float g = rtf::dir_scale(reach, bx, by, bz);
+    job.bx[slot] = bx; job.by[slot] = by; job.bz[slot] = bz;
+    job.g[slot] = (reach <= reach_max) ? g : -g;
+}
+
+struct SharedOrigin { // the shared origin of a launch and the validity range of its cones
+    float origin[3];
+    float center[3];
+    float radius;
+    float reach_max;
+    float sign;
+};
+
+struct Scratch {
+    float *sox, *soy, *soz;    // color: r.origin as the light loop mutates it (raycol_cs.glsl:45)
+    float *lr, *lg, *lb;       // color: `light` accumulator
+    int *lit;                  // color: !shadowed
+    int *occ;                  // shadow ray of the current light is occluded
+    unsigned long long *best;  // intersect: (float bits of t) << 32 | primitive index, minimum wins
+};
+
+constexpr unsigned long long BEST_NONE = 0x7f80000000000000ull; // t = +inf, index 0 (trace.glsl:123,133)
+
+// true iff the predicate holds in any lane of the wavefront (one v_cmp + a scalar test)
+__device__ __forceinline__ bool any64(bool b) { return __builtin_amdgcn_ballot_w64(b) != 0ull; }
+
 __device__ __forceinline__ v3 vpos(const rt_vertex *__restrict__ v, int i)
 {
     const float4 p = *reinterpret_cast<const float4 *>(v + i);
     return rtx::V(p.x, p.y, p.z);
 }
+
+// ---------------------------------------------------------------------------
+// intersect, part 1 of 3  ("OpenGL Raytracer/rayintersect_cs.glsl":6-12)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void intersect_setup_kernel(RaySoA r, const int *__restrict__ list,
+                                                                const int *__restrict__ count, int n_fixed, Job job,
+                                                                unsigned long long *__restrict__ best, int shared,
+                                                                SharedOrigin so)
+{
+    const int n = count ? *count : n_fixed;
+    const int slot = blockIdx.x * BLOCK + threadIdx.x;
+    if (slot >= n) return;
+    const int i = list ? list[slot] : slot;
+    v3 o = rtx::V(r.ox[i], r.oy[i], r.oz[i]);
+    const v3 d = rtx::V(r.dx[i], r.dy[i], r.dz[i]);
+    o = rtx::add(o, rtx::muls(d, 0.001f)); // r.origin = r.origin + r.dir * 0.001
+    job.ox[slot] = o.x; job.oy[slot] = o.y; job.oz[slot] = o.z;
+    job.dx[slot] = d.x; job.dy[slot] = d.y; job.dz[slot] = d.z;
+    best[slot] = BEST_NONE;
+    if (shared) prepare_shared(job, slot, o, d, so.origin, so.center, so.radius, so.reach_max, so.sign);
+}
+
+// ---------------------------------------------------------------------------
+// traversal: every ray of a list against a range of triangles.
+//
+//   K       rays per lane (256 K rays per workgroup)
+//   FORM    0: filter for arbitrary rays; 1: every ray's line passes through p.origin
+//           (rays fresh from raygen: the camera; shadow rays: the light)
+//   ANYHIT  false: closest hit -- the reference's strict (t > 0 && t < best) in triangle
+//                  order per lane; lanes/workgroups that scan different triangle ranges
+//                  merge with a 64-bit atomicMin on (t bits, index), which keeps the
+//                  smallest t and, among equal t, the lowest index: exactly what the
+//                  sequential loop trace.glsl:135-157 keeps.
+//           true : shadow query -- "is any primitive accepted with 0 < t <= tmax", which is
+//                  all raycol_cs.glsl:50 reads of the shadow trace; sets occ[slot].
+//   EXACT   evaluate the reference arithmetic on every pair (validation mode).
+//
+// grid = (ray blocks, triangle sub-ranges): blockIdx.y scans `tiles_per_y` LDS tiles
+// starting at tri_begin.  Filter records stream through LDS in tiles of 256 triangles
+// and are read back with wave-uniform addresses (LDS broadcast); the pairs the filter
+// cannot reject go through the reference's own Moller-Trumbore arithmetic.
+// ---------------------------------------------------------------------------
+struct TraverseParams {
+    Job job;
+    const int *alist;  // slots to trace, or nullptr for 0..n-1
+    const int *count;  // number of entries (device), or nullptr -> n
+    int n;
+    const rtf::TriRec *recs;
+    const rtf::ConeRec *cones; // FORM 1 only
+    const rt_vertex *verts;
+    int num_tris;
+    int tri_begin, tri_end; // multiple of TILE / end of range
+    int tiles_per_y;
+    float center[3];
+    float radius;
+    float origin[3];
+    float reach_max;   // FORM 1: the cones are valid for rays whose reach is <= this
+    float dir_sign;    // FORM 1: +1 the triangles lie along +dir from the origin (camera rays),
+                       //         -1 along -dir (shadow rays run towards the light)
+    unsigned long long *best;
+    int *occ;
+    unsigned long long *counters;
+};
 
 // cooperative copy of one tile of filter records into LDS; records past the end
 // of the mesh are NaN (no ray passes them)
@@ -246,176 +371,369 @@ __device__ __forceinline__ void load_tile(float4 *tile4, const rtf::TriRec *__re
     }
 }
 
-struct TraceParams {
-    RaySoA rays;
-    const int *list;   // ray indices, or nullptr for the identity
-    const int *count;  // number of list entries (device), or nullptr -> n
-    int n;             // number of rays when count == nullptr
-    const rtf::TriRec *recs;
-    const rt_vertex *verts;
-    int num_tris;
-    float center[3];   // bounding sphere of the mesh
-    float radius;
-    float origin[3];   // shared origin (FORM 1)
-    float cam_pos[3];
-    float *depth;
-    unsigned long long *counters;
-};
-
-// ---------------------------------------------------------------------------
-// intersect  ("OpenGL Raytracer/rayintersect_cs.glsl":1-34 with trace.glsl:121-184)
-//
-// K rays per lane, 256 K rays per workgroup.  FORM 0: any rays; FORM 1: every
-// ray's line passes through p.origin (rays fresh from raygen).  EXACT: evaluate
-// the reference arithmetic on every pair (validation mode).
-//
-// Order of acceptance: a lane walks the triangles in index order and accepts with
-// the reference's strict (t > 0 && t < best), so ties keep the lowest index, as the
-// sequential loop trace.glsl:135-157 does; the two spheres follow (:164-183).
-// The triangle normal depends only on the winning triangle, so it is formed once
-// after the loop instead of on every improvement.
-// ---------------------------------------------------------------------------
-template <int K, int FORM, bool EXACT>
-__global__ __launch_bounds__(BLOCK) void closest_hit_kernel(TraceParams p)
+// the reference's test on one pair, and what it does to the lane's running result
+template <bool ANYHIT>
+__device__ __forceinline__ void exact_pair(v3 o, v3 d, v3 X, v3 Y, v3 Z, int tri, float &tbest, int &idbest,
+                                           bool &occ)
 {
-    __shared__ float4 tile4[TILE * 3];
-    __shared__ float xr[6][K][BLOCK]; // exact (offset origin, direction) per ray; column tid is private to thread tid
+    float t;
+    if (rtx::ray_vs_triangle(o, d, X, Y, Z, t)) {
+        if (ANYHIT) {
+            if (t > 0.0f && t <= tbest) occ = true;
+        } else if (t > 0.0f && t < tbest) {
+            tbest = t;
+            idbest = tri;
+        }
+    }
+}
+
+constexpr int CONE_TILE = 1024; // triangles per LDS tile of cone records (16 KiB)
+// candidate queue entries per wavefront: one triangle can add 64 K entries, and draining
+// starts once fewer than that are free
+__host__ __device__ constexpr int qcap(int K) { return 64 * K + 256; }
+
+// number of set bits of `mask` below this lane
+__device__ __forceinline__ int lanes_below(unsigned long long mask)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32),
+                                          __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
+}
+
+template <int K, int FORM, bool ANYHIT, bool EXACT>
+__global__ __launch_bounds__(BLOCK) void traverse_kernel(TraverseParams p)
+{
+    // FORM 0: tiles of 256 edge records (12 KiB).  FORM 1: tiles of 1024 cone records (16 KiB);
+    // the edge records are only touched by the rare second level and stay in global memory.
+    __shared__ float4 lds4[FORM == 1 ? CONE_TILE : TILE * 3];
+    constexpr int TSZ = (FORM == 1) ? CONE_TILE : TILE;
 
     const int tid = threadIdx.x;
     const int n = p.count ? *p.count : p.n;
-    const int slot0 = blockIdx.x * (BLOCK * K);
-    if (slot0 >= n) return; // whole workgroup leaves together
+    const int s0 = blockIdx.x * (BLOCK * K);
+    if (s0 >= n) return; // whole workgroup leaves together
+    // p.tiles_per_y counts tiles of 256 triangles; ranges start on multiples of 1024
+    const int t_begin = p.tri_begin + blockIdx.y * p.tiles_per_y * TILE;
+    const int t_end = min(t_begin + p.tiles_per_y * TILE, p.tri_end);
+    if (t_begin >= t_end) return;
 
-    int ridx[K];
+    int slot[K];
     bool valid[K];
-    float ox[K], oy[K], oz[K], hx[K], hy[K], hz[K], tbest[K];
+    // FORM 0: a = ray origin, b = direction * g, d = direction.
+    // FORM 1: b = unit direction (times dir_sign); a and d are unused.
+    float ax[K], ay[K], az[K], bx[K], by[K], bz[K], dx[K], dy[K], dz[K], g[K], tbest[K];
     int idbest[K];
+    bool occ[K], wild[K];
+    const float qn = __int_as_float(0x7fc00000);
 
 #pragma unroll
     for (int k = 0; k < K; k++) {
-        const int slot = slot0 + k * BLOCK + tid;
-        valid[k] = slot < n;
-        ridx[k] = valid[k] ? (p.list ? p.list[slot] : slot) : 0;
-        const float qn = __int_as_float(0x7fc00000);
+        const int s = s0 + k * BLOCK + tid;
+        valid[k] = s < n;
+        slot[k] = valid[k] ? (p.alist ? p.alist[s] : s) : 0;
         v3 o = rtx::V(qn, qn, qn), d = o;
+        float tmax = 0.0f;
         if (valid[k]) {
-            o = rtx::V(p.rays.ox[ridx[k]], p.rays.oy[ridx[k]], p.rays.oz[ridx[k]]);
-            d = rtx::V(p.rays.dx[ridx[k]], p.rays.dy[ridx[k]], p.rays.dz[ridx[k]]);
+            o = rtx::V(p.job.ox[slot[k]], p.job.oy[slot[k]], p.job.oz[slot[k]]);
+            d = rtx::V(p.job.dx[slot[k]], p.job.dy[slot[k]], p.job.dz[slot[k]]);
+            if (ANYHIT) {
+                tmax = p.job.tmax[slot[k]];
+                if (p.occ[slot[k]] != 0) valid[k] = false; // already decided (tmax not finite)
+            }
         }
-        // r.origin = r.origin + r.dir * 0.001   (rayintersect_cs.glsl:12)
-        o = rtx::add(o, rtx::muls(d, 0.001f));
-        xr[0][k][tid] = o.x; xr[1][k][tid] = o.y; xr[2][k][tid] = o.z;
-        xr[3][k][tid] = d.x; xr[4][k][tid] = d.y; xr[5][k][tid] = d.z;
-        float reach;
+        if (!valid[k]) o = d = rtx::V(qn, qn, qn);
+        wild[k] = false;
         if (FORM == 0) {
             v3 oc = rtx::V(o.x - p.center[0], o.y - p.center[1], o.z - p.center[2]);
-            reach = sqrtf(rtx::dot(oc, oc)) + 3.0f * p.radius;
+            const float reach = sqrtf(rtx::dot(oc, oc)) + 3.0f * p.radius;
+            g[k] = rtf::dir_scale(reach, d.x, d.y, d.z);
+            ax[k] = o.x; ay[k] = o.y; az[k] = o.z;
+            dx[k] = d.x; dy[k] = d.y; dz[k] = d.z;
+            bx[k] = d.x * g[k]; by[k] = d.y * g[k]; bz[k] = d.z * g[k];
         } else {
-            v3 O = rtx::V(p.origin[0], p.origin[1], p.origin[2]);
-            v3 C = rtx::V(p.center[0], p.center[1], p.center[2]);
-            reach = sqrtf(rtx::dot(O, O)) + sqrtf(rtx::dot(o, o)) + sqrtf(rtx::dot(C, C)) + 3.0f * p.radius;
-        }
-        const float sc = rtf::dir_scale(reach, d.x, d.y, d.z);
-        ox[k] = o.x; oy[k] = o.y; oz[k] = o.z;
-        hx[k] = d.x * sc; hy[k] = d.y * sc; hz[k] = d.z * sc;
-        tbest[k] = INFINITY; // r.t = 1.0 / 0.0   (trace.glsl:123)
-        idbest[k] = 0;       // r.primitiveID = 0 (trace.glsl:133)
-    }
-
-    unsigned long long n_cand = 0;
-    const float *tile = reinterpret_cast<const float *>(tile4);
-
-    for (int tile_base = 0; tile_base < p.num_tris; tile_base += TILE) {
-        __syncthreads();
-        load_tile(tile4, p.recs, tile_base, p.num_tris, tid);
-        __syncthreads();
-        const int cnt = min(TILE, p.num_tris - tile_base);
-        for (int j = 0; j < cnt; j++) {
-            const float *rec = tile + j * REC_FLOATS; // wave-uniform address: LDS broadcast
-            float g[K];
-            float G = -INFINITY;
-#pragma unroll
-            for (int k = 0; k < K; k++) {
-                if (FORM == 0) g[k] = rtf::filter_general(rec, ox[k], oy[k], oz[k], hx[k], hy[k], hz[k]);
-                else g[k] = rtf::filter_origin(rec, hx[k], hy[k], hz[k]);
-                G = fmaxf(G, g[k]);
+            bx[k] = by[k] = bz[k] = qn;
+            g[k] = 1.0f;
+            if (valid[k]) {
+                bx[k] = p.job.bx[slot[k]]; by[k] = p.job.by[slot[k]]; bz[k] = p.job.bz[slot[k]];
+                g[k] = p.job.g[slot[k]];
             }
-            const bool any_pass = EXACT ? true : (G >= -1.0f);
-            if (__any(any_pass)) {
-                // rare path: the reference's own arithmetic on the pairs that passed
-                const int tri = tile_base + j;
-                const v3 X = vpos(p.verts, 3 * tri), Y = vpos(p.verts, 3 * tri + 1), Z = vpos(p.verts, 3 * tri + 2);
+            ax[k] = ay[k] = az[k] = dx[k] = dy[k] = dz[k] = 0.0f;
+            // outside the range the cones were built for (or not comparable): the cone test is
+            // skipped for the whole wave and the edge filter decides
+            wild[k] = valid[k] && !(g[k] > 0.0f);
+        }
+        tbest[k] = ANYHIT ? tmax : INFINITY;
+        idbest[k] = 0;
+        occ[k] = !valid[k];
+    }
+    bool any_wild = false;
 #pragma unroll
-                for (int k = 0; k < K; k++) {
-                    const bool pass = EXACT ? valid[k] : (g[k] >= -1.0f);
-                    if (!EXACT) n_cand += __popcll(__ballot(pass));
-                    if (pass) {
-                        const v3 o = rtx::V(xr[0][k][tid], xr[1][k][tid], xr[2][k][tid]);
-                        const v3 d = rtx::V(xr[3][k][tid], xr[4][k][tid], xr[5][k][tid]);
-                        float t;
-                        if (rtx::ray_vs_triangle(o, d, X, Y, Z, t)) {
-                            if (t > 0.0f && t < tbest[k]) {
-                                tbest[k] = t;
-                                idbest[k] = tri;
-                            }
-                        }
+    for (int k = 0; k < K; k++) any_wild = any_wild || wild[k];
+    const bool wave_wild = any64(any_wild);
+
+    unsigned long long n_cand = 0, n_slow = 0;
+    int tris_done = 0;
+
+    // second level (FORM 1) / candidate handling for one triangle; `pass` says which of the
+    // lane's rays go to the reference arithmetic
+    auto exact_stage = [&](int tri, const bool (&pass)[K]) {
+        const v3 X = vpos(p.verts, 3 * tri), Y = vpos(p.verts, 3 * tri + 1), Z = vpos(p.verts, 3 * tri + 2);
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            if (!EXACT) n_cand += __popcll(__ballot(pass[k]));
+            if (pass[k] && !(ANYHIT && occ[k])) {
+                v3 o, d;
+                if (FORM == 0) {
+                    o = rtx::V(ax[k], ay[k], az[k]);
+                    d = rtx::V(dx[k], dy[k], dz[k]);
+                } else {
+                    o = rtx::V(p.job.ox[slot[k]], p.job.oy[slot[k]], p.job.oz[slot[k]]);
+                    d = rtx::V(p.job.dx[slot[k]], p.job.dy[slot[k]], p.job.dz[slot[k]]);
+                }
+                exact_pair<ANYHIT>(o, d, X, Y, Z, tri, tbest[k], idbest[k], occ[k]);
+            }
+        }
+    };
+
+    // FORM 1: queue of (triangle, ray) pairs that passed the cone test, one per wavefront
+    __shared__ unsigned int queue_all[(FORM == 1 && !EXACT) ? (BLOCK / 64) * qcap(K) : 1];
+    unsigned int *queue = queue_all + ((FORM == 1 && !EXACT) ? (tid >> 6) * qcap(K) : 0);
+    int qcount = 0; // wave-uniform
+    const int lane = tid & 63;
+
+    // Level 2 and the reference arithmetic for queued pairs, one pair per lane.
+    auto drain = [&](bool all) {
+#ifdef RT_DBG_NO_DRAIN
+        qcount = 0;
+        return;
+#endif
+        while (qcount >= 64 || (all && qcount > 0)) {
+            const int take = qcount >= 64 ? 64 : qcount;
+            qcount -= take;
+            bool pass2 = false;
+            int tri = 0, sl = 0;
+            v3 o = rtx::V(0.0f, 0.0f, 0.0f), d = o;
+            if (lane < take) {
+                const unsigned int e = queue[qcount + lane];
+                const int r = (int)(e & 2047u);
+                tri = t_begin + (int)(e >> 11);
+                const int s = s0 + r;
+                sl = p.alist ? p.alist[s] : s;
+                // the edge filter on the unit direction, scaled (two-sided: the sign is irrelevant)
+                const float gg = fabsf(p.job.g[sl]);
+                float lo, hi;
+                rtf::filter_origin_lohi(reinterpret_cast<const float *>(p.recs + tri), p.job.bx[sl] * gg,
+                                        p.job.by[sl] * gg, p.job.bz[sl] * gg, lo, hi);
+                pass2 = fmaxf(lo, -hi) >= -1.0f;
+            }
+            n_cand += __popcll(__builtin_amdgcn_ballot_w64(pass2));
+            if (pass2) {
+                o = rtx::V(p.job.ox[sl], p.job.oy[sl], p.job.oz[sl]);
+                d = rtx::V(p.job.dx[sl], p.job.dy[sl], p.job.dz[sl]);
+                const v3 X = vpos(p.verts, 3 * tri), Y = vpos(p.verts, 3 * tri + 1), Z = vpos(p.verts, 3 * tri + 2);
+                float t;
+                if (rtx::ray_vs_triangle(o, d, X, Y, Z, t)) {
+                    if (ANYHIT) {
+                        if (t > 0.0f && t <= p.job.tmax[sl]) p.occ[sl] = 1;
+                    } else if (t > 0.0f) {
+                        const unsigned long long key =
+                            ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)(unsigned int)tri;
+                        atomicMin(&p.best[sl], key);
                     }
                 }
             }
         }
-    }
+    };
 
-    if ((tid & 63) == 0) add_counter(p.counters, C_CH_CAND, n_cand);
+    for (int tile_base = t_begin; tile_base < t_end; tile_base += TSZ) {
+        if (ANYHIT) {
+            bool all_occ = true;
+#pragma unroll
+            for (int k = 0; k < K; k++) all_occ = all_occ && occ[k];
+            // barrier + early exit: leave when every ray of the workgroup is occluded
+            if (__syncthreads_and(all_occ ? 1 : 0)) break;
+        } else {
+            __syncthreads();
+        }
+        const int tile_n = min(TSZ, t_end - tile_base); // triangles of this tile that belong to the range
+        if (FORM == 1) {
+            const float4 *cs = reinterpret_cast<const float4 *>(p.cones);
+#pragma unroll
+            for (int i = 0; i < CONE_TILE / BLOCK; i++) {
+                const int e = i * BLOCK + tid;
+                lds4[e] = (e < tile_n && tile_base + e < p.num_tris) ? cs[tile_base + e]
+                                                                    : make_float4(0.0f, 0.0f, 0.0f, 2.0f);
+            }
+        } else {
+            load_tile(lds4, p.recs, tile_base, p.num_tris, tid);
+        }
+        __syncthreads();
+        tris_done += tile_n;
+
+        if (EXACT) {
+            for (int j = 0; j < tile_n; j++) {
+                bool pass[K];
+#pragma unroll
+                for (int k = 0; k < K; k++) pass[k] = valid[k];
+                if (tile_base + j < p.num_tris) exact_stage(tile_base + j, pass);
+            }
+        } else if (FORM == 0) {
+            const float *tile = reinterpret_cast<const float *>(lds4);
+#pragma unroll 2
+            for (int j = 0; j < TILE; j++) {
+                const float *rec = tile + j * REC_FLOATS; // wave-uniform address: LDS broadcast
+                float lo[K], hi[K];
+#pragma unroll
+                for (int k = 0; k < K; k++)
+                    rtf::filter_general_lohi(rec, ax[k], ay[k], az[k], bx[k], by[k], bz[k], lo[k], hi[k]);
+                // some ray passes  <=>  max over rays of max(lo, -hi) >= -1
+                float G = fmaxf(lo[0], -hi[0]);
+#pragma unroll
+                for (int k = 1; k < K; k++) G = fmaxf(fmaxf(G, lo[k]), -hi[k]);
+                if (any64(G >= -1.0f)) {
+                    n_slow++;
+                    bool pass[K];
+#pragma unroll
+                    for (int k = 0; k < K; k++) pass[k] = fmaxf(lo[k], -hi[k]) >= -1.0f;
+                    exact_stage(tile_base + j, pass);
+                }
+            }
+        } else {
+            // level 1: one dot product per pair against the triangle's cone of directions,
+            // four triangles per step so that their LDS reads are in flight together.  Pairs
+            // inside the cone are queued; full batches of 64 are handled with all lanes busy.
+            for (int j = 0; j < CONE_TILE; j += 4) {
+                const float4 c0 = lds4[j], c1 = lds4[j + 1], c2 = lds4[j + 2], c3 = lds4[j + 3];
+                float t0[K], t1[K], t2[K], t3[K];
+#pragma unroll
+                for (int k = 0; k < K; k++) {
+                    t0[k] = fmaf(c0.z, bz[k], fmaf(c0.y, by[k], c0.x * bx[k]));
+                    t1[k] = fmaf(c1.z, bz[k], fmaf(c1.y, by[k], c1.x * bx[k]));
+                    t2[k] = fmaf(c2.z, bz[k], fmaf(c2.y, by[k], c2.x * bx[k]));
+                    t3[k] = fmaf(c3.z, bz[k], fmaf(c3.y, by[k], c3.x * bx[k]));
+                }
+                float G0 = t0[0], G1 = t1[0], G2 = t2[0], G3 = t3[0];
+#pragma unroll
+                for (int k = 1; k < K; k++) {
+                    G0 = fmaxf(G0, t0[k]); G1 = fmaxf(G1, t1[k]);
+                    G2 = fmaxf(G2, t2[k]); G3 = fmaxf(G3, t3[k]);
+                }
+                const bool h0 = G0 >= c0.w, h1 = G1 >= c1.w, h2 = G2 >= c2.w, h3 = G3 >= c3.w;
+#ifndef RT_DBG_NO_SLOW
+                if (any64(h0 || h1 || h2 || h3) || wave_wild) {
+                    n_slow++;
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const float w = (u == 0) ? c0.w : (u == 1) ? c1.w : (u == 2) ? c2.w : c3.w;
+                        const bool hu = (u == 0) ? h0 : (u == 1) ? h1 : (u == 2) ? h2 : h3;
+                        if (!(any64(hu) || wave_wild)) continue;
+                        const unsigned int trel = (unsigned int)(tile_base + j + u - t_begin);
+#pragma unroll
+                        for (int k = 0; k < K; k++) {
+                            const float t = (u == 0) ? t0[k] : (u == 1) ? t1[k] : (u == 2) ? t2[k] : t3[k];
+                            const bool in = ((t >= w) || wild[k]) && (w < 2.0f) && !occ[k];
+                            const unsigned long long m = __builtin_amdgcn_ballot_w64(in);
+                            if (m) {
+                                if (in) queue[qcount + lanes_below(m)] = (trel << 11) | (unsigned int)(k * BLOCK + tid);
+                                qcount += __popcll(m);
+                            }
+                        }
+                        if (qcount >= qcap(K) - 64 * K) drain(false);
+                    }
+                }
+#else
+                if (any64(h0 || h1 || h2 || h3) || wave_wild) n_slow++;
+#endif
+            }
+            if (ANYHIT) {
+                // results of drained batches live in global memory: refresh this lane's view
+#pragma unroll
+                for (int k = 0; k < K; k++)
+                    if (valid[k] && !occ[k]) occ[k] = p.occ[slot[k]] != 0;
+            }
+        }
+    }
+    if (FORM == 1 && !EXACT) drain(true);
+
+    if ((tid & 63) == 0) {
+        add_counter(p.counters, ANYHIT ? C_SH_CAND : C_CH_CAND, n_cand);
+        add_counter(p.counters, ANYHIT ? C_SH_SLOW : C_CH_SLOW, n_slow);
+    }
     if (tid == 0) {
-        const int mine = min(BLOCK * K, n - slot0);
-        add_counter(p.counters, C_CH_RAYS, (unsigned long long)mine);
-        add_counter(p.counters, C_CH_PAIRS, (unsigned long long)mine * (unsigned long long)p.num_tris);
+        const int mine = min(BLOCK * K, n - s0);
+        add_counter(p.counters, ANYHIT ? C_SH_PAIRS : C_CH_PAIRS,
+                    (unsigned long long)mine * (unsigned long long)min(tris_done, p.num_tris - t_begin));
     }
 
-    // epilogue: spheres, normal, and the rest of rayintersect_cs.glsl:16-33
 #pragma unroll
     for (int k = 0; k < K; k++) {
         if (!valid[k]) continue;
-        const int i = ridx[k];
-        const v3 o = rtx::V(xr[0][k][tid], xr[1][k][tid], xr[2][k][tid]);
-        const v3 d = rtx::V(xr[3][k][tid], xr[4][k][tid], xr[5][k][tid]);
-        float tb = tbest[k];
-        int id = idbest[k];
-        int kind = (tb < INFINITY) ? 1 : 0; // 0 none, 1 triangle, 2 sphere
-        v3 nrm = rtx::V(0.0f, 0.0f, 0.0f);
+        if (ANYHIT) {
+            if (occ[k]) p.occ[slot[k]] = 1; // every writer writes 1
+        } else if (tbest[k] < INFINITY) {
+            const unsigned long long key =
+                ((unsigned long long)__float_as_uint(tbest[k]) << 32) | (unsigned long long)(unsigned int)idbest[k];
+            atomicMin(&p.best[slot[k]], key);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// intersect, part 3 of 3: the two spheres (trace.glsl:164-183), the normal of the
+// winning primitive, and rayintersect_cs.glsl:16-33.  The triangle normal depends
+// only on the winning triangle, so it is formed once here instead of on every
+// improvement inside the loop.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void intersect_finish_kernel(RaySoA r, const int *__restrict__ list,
+                                                                 const int *__restrict__ count, int n_fixed, Job job,
+                                                                 const unsigned long long *__restrict__ best,
+                                                                 const rt_vertex *__restrict__ verts, int num_tris,
+                                                                 Camera cam, float *__restrict__ depth,
+                                                                 unsigned long long *counters)
+{
+    const int n = count ? *count : n_fixed;
+    const int slot = blockIdx.x * BLOCK + threadIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x == 0) add_counter(counters, C_CH_RAYS, (unsigned long long)n);
+    if (slot >= n) return;
+    const int i = list ? list[slot] : slot;
+    const v3 o = rtx::V(job.ox[slot], job.oy[slot], job.oz[slot]);
+    const v3 d = rtx::V(job.dx[slot], job.dy[slot], job.dz[slot]);
+    const unsigned long long key = best[slot];
+    float tb = __uint_as_float((unsigned int)(key >> 32));
+    int id = (int)(unsigned int)(key & 0xffffffffull);
+    int kind = (tb < INFINITY) ? 1 : 0; // 0 none, 1 triangle, 2 sphere
+    v3 nrm = rtx::V(0.0f, 0.0f, 0.0f);
 #pragma unroll
-        for (int s = 0; s < 2; s++) {
-            float ts;
-            if (rtx::ray_sphere(o, d, rtx::sphere_center(s), rtx::sphere_radius(s), ts)) {
-                if (ts > 0.0f && ts < tb) {
-                    tb = ts;
-                    id = p.num_tris + s;
-                    kind = 2;
-                    v3 pt = rtx::add(o, rtx::muls(d, tb));
-                    nrm = rtx::normalize(rtx::sub(pt, rtx::sphere_center(s)));
-                }
+    for (int s = 0; s < 2; s++) {
+        float ts;
+        if (rtx::ray_sphere(o, d, rtx::sphere_center(s), rtx::sphere_radius(s), ts)) {
+            if (ts > 0.0f && ts < tb) {
+                tb = ts;
+                id = num_tris + s;
+                kind = 2;
+                v3 pt = rtx::add(o, rtx::muls(d, tb));
+                nrm = rtx::normalize(rtx::sub(pt, rtx::sphere_center(s)));
             }
         }
-        if (kind == 1) {
-            const v3 X = vpos(p.verts, 3 * id), Y = vpos(p.verts, 3 * id + 1), Z = vpos(p.verts, 3 * id + 2);
-            nrm = rtx::normalize(rtx::cross(rtx::sub(X, Z), rtx::sub(Y, Z)));
-        } else if (kind == 0) {
-            nrm = rtx::V(p.rays.nx[i], p.rays.ny[i], p.rays.nz[i]); // a miss keeps the old normal
-        }
-        v3 ob = rtx::sub(o, rtx::muls(d, 0.001f));
-        if (isinf(tb)) id = -2;
-        ob = rtx::add(ob, rtx::muls(d, tb));
-        const v3 dn = rtx::sub(d, rtx::muls(nrm, 2.0f * rtx::dot(d, nrm)));
-        p.rays.ox[i] = ob.x; p.rays.oy[i] = ob.y; p.rays.oz[i] = ob.z;
-        p.rays.dx[i] = dn.x; p.rays.dy[i] = dn.y; p.rays.dz[i] = dn.z;
-        p.rays.t[i] = tb;
-        p.rays.id[i] = id;
-        if (kind != 0) {
-            p.rays.nx[i] = nrm.x; p.rays.ny[i] = nrm.y; p.rays.nz[i] = nrm.z;
-            p.rays.cx[i] = 0.0f; p.rays.cy[i] = 0.0f; p.rays.cz[i] = (kind == 2) ? 1.0f : 0.0f;
-        }
-        p.depth[i] = rtx::distance3(ob, rtx::V(p.cam_pos[0], p.cam_pos[1], p.cam_pos[2]));
     }
+    if (kind == 1) {
+        const v3 X = vpos(verts, 3 * id), Y = vpos(verts, 3 * id + 1), Z = vpos(verts, 3 * id + 2);
+        nrm = rtx::normalize(rtx::cross(rtx::sub(X, Z), rtx::sub(Y, Z)));
+    } else if (kind == 0) {
+        nrm = rtx::V(r.nx[i], r.ny[i], r.nz[i]); // a miss keeps the old normal
+    }
+    v3 ob = rtx::sub(o, rtx::muls(d, 0.001f));
+    if (isinf(tb)) id = -2;
+    ob = rtx::add(ob, rtx::muls(d, tb));
+    const v3 dn = rtx::sub(d, rtx::muls(nrm, 2.0f * rtx::dot(d, nrm)));
+    r.ox[i] = ob.x; r.oy[i] = ob.y; r.oz[i] = ob.z;
+    r.dx[i] = dn.x; r.dy[i] = dn.y; r.dz[i] = dn.z;
+    r.t[i] = tb;
+    r.id[i] = id;
+    if (kind != 0) {
+        r.nx[i] = nrm.x; r.ny[i] = nrm.y; r.nz[i] = nrm.z;
+        r.cx[i] = 0.0f; r.cy[i] = 0.0f; r.cz[i] = (kind == 2) ? 1.0f : 0.0f;
+    }
+    depth[i] = rtx::distance3(ob, rtx::V(cam.pos[0], cam.pos[1], cam.pos[2]));
 }
 
 // ---------------------------------------------------------------------------
@@ -425,214 +743,131 @@ __global__ __launch_bounds__(BLOCK) void closest_hit_kernel(TraceParams p)
 // miss: origin + dir * inf) gives lightDir = NaN, d = NaN, so `lightRay.t > d` is
 // false for every light and the pixel is vec3(0.1); compact_kernel<1> wrote it.
 //
-// The shadow query only uses `lightRay.t > d` (raycol_cs.glsl:50), i.e. "no
-// primitive is accepted with 0 < t <= d", so traversal is any-hit with early
-// exit.  The shadow ray's line passes through the light, so the shared-origin
-// filter with the light as origin applies; the exact test uses the reference's own
-// origin (r.origin + lightDir * 1e-7) and direction.
+// Per light:  shadow_setup -> { traverse<ANYHIT> over a chunk of triangles -> compact the
+// rays that are still unoccluded } x chunks -> shadow_finish (spheres + Phong).  Dropping
+// occluded rays between chunks is the early exit: they cost nothing in later chunks.
+// The shadow ray's line passes through the light, so the shared-origin filter with the
+// light as origin applies; the exact test uses the reference's own origin
+// (r.origin + lightDir * 1e-7) and direction.
 // ---------------------------------------------------------------------------
-struct ShadeParams {
-    RaySoA rays;
-    const int *list;
-    const int *count;
-    const rtf::TriRec *light_recs; // num_lights arrays of rec_stride records
-    size_t rec_stride;
-    const rt_vertex *verts;
-    int num_vertices;
-    int num_tris;
-    float center[3];
-    float radius;
-    float cam_pos[3];
-    int num_lights;
-    rt_light lights[RT_MAX_LIGHTS];
-    const uint32_t *tex;
-    int tex_w, tex_h;
-    uint32_t *fb;
-    unsigned long long *counters;
-};
-
-template <int K, bool EXACT>
-__global__ __launch_bounds__(BLOCK) void shade_kernel(ShadeParams p)
+__global__ __launch_bounds__(BLOCK) void color_begin_kernel(RaySoA r, const int *__restrict__ list0,
+                                                            const int *__restrict__ count, Scratch s)
 {
-    __shared__ float4 tile4[TILE * 3];
-    __shared__ float xr[6][K][BLOCK];
+    const int slot = blockIdx.x * BLOCK + threadIdx.x;
+    if (slot >= *count) return;
+    const int i = list0[slot];
+    s.sox[slot] = r.ox[i]; s.soy[slot] = r.oy[i]; s.soz[slot] = r.oz[i];
+    s.lr[slot] = 0.0f; s.lg[slot] = 0.0f; s.lb[slot] = 0.0f;
+    s.lit[slot] = 0;
+}
 
-    const int tid = threadIdx.x;
-    const int n = *p.count;
-    const int slot0 = blockIdx.x * (BLOCK * K);
-    if (slot0 >= n) return;
-    const int mine = min(BLOCK * K, n - slot0);
+// raycol_cs.glsl:39-47
+__global__ __launch_bounds__(BLOCK) void shadow_setup_kernel(const int *__restrict__ count, Scratch s, Job job,
+                                                             float lx, float ly, float lz, SharedOrigin so,
+                                                             unsigned long long *counters)
+{
+    const int n = *count;
+    const int slot = blockIdx.x * BLOCK + threadIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x == 0) add_counter(counters, C_SH_RAYS, (unsigned long long)n);
+    if (slot >= n) return;
+    const v3 lpos = rtx::V(lx, ly, lz);
+    v3 o = rtx::V(s.sox[slot], s.soy[slot], s.soz[slot]);
+    const v3 ld = rtx::normalize(rtx::sub(lpos, o));
+    const v3 o2 = rtx::add(o, rtx::muls(ld, 0.0000001f)); // shadow-ray origin
+    o = rtx::sub(o, rtx::muls(ld, 0.0000001f));           // r.origin = r.origin - lightDir * 1e-7
+    s.sox[slot] = o.x; s.soy[slot] = o.y; s.soz[slot] = o.z;
+    const float dist = rtx::distance3(lpos, o);
+    job.ox[slot] = o2.x; job.oy[slot] = o2.y; job.oz[slot] = o2.z;
+    job.dx[slot] = ld.x; job.dy[slot] = ld.y; job.dz[slot] = ld.z;
+    job.tmax[slot] = dist;
+    s.occ[slot] = (dist < INFINITY) ? 0 : 1; // `lightRay.t > d` can only hold for finite d
+    prepare_shared(job, slot, o2, ld, so.origin, so.center, so.radius, so.reach_max, so.sign);
+}
 
-    int ridx[K];
-    bool valid[K], lit[K];
-    float ox[K], oy[K], oz[K], nx[K], ny[K], nz[K];
-    float lr[K], lg[K], lb[K];
+// spheres of the shadow trace, then raycol_cs.glsl:50-79 for the rays that reach the light
+__global__ __launch_bounds__(BLOCK) void shadow_finish_kernel(RaySoA r, const int *__restrict__ list0,
+                                                              const int *__restrict__ alist,
+                                                              const int *__restrict__ acount, int n_fixed, Scratch s,
+                                                              Job job, rt_light light, Camera cam)
+{
+    const int n = acount ? *acount : n_fixed;
+    const int a = blockIdx.x * BLOCK + threadIdx.x;
+    if (a >= n) return;
+    const int slot = alist ? alist[a] : a;
+    if (s.occ[slot] != 0) return;
+    const v3 o2 = rtx::V(job.ox[slot], job.oy[slot], job.oz[slot]);
+    const v3 ld = rtx::V(job.dx[slot], job.dy[slot], job.dz[slot]);
+    const float dist = job.tmax[slot];
 #pragma unroll
-    for (int k = 0; k < K; k++) {
-        const int slot = slot0 + k * BLOCK + tid;
-        valid[k] = slot < n;
-        ridx[k] = valid[k] ? p.list[slot] : 0;
-        const float qn = __int_as_float(0x7fc00000);
-        ox[k] = oy[k] = oz[k] = qn;
-        nx[k] = ny[k] = nz[k] = 0.0f;
-        if (valid[k]) {
-            ox[k] = p.rays.ox[ridx[k]]; oy[k] = p.rays.oy[ridx[k]]; oz[k] = p.rays.oz[ridx[k]];
-            nx[k] = p.rays.nx[ridx[k]]; ny[k] = p.rays.ny[ridx[k]]; nz[k] = p.rays.nz[ridx[k]];
-        }
-        lit[k] = false;
-        lr[k] = lg[k] = lb[k] = 0.0f;
+    for (int sp = 0; sp < 2; sp++) {
+        float ts;
+        if (rtx::ray_sphere(o2, ld, rtx::sphere_center(sp), rtx::sphere_radius(sp), ts))
+            if (ts > 0.0f && ts <= dist) return; // occluded by a sphere
     }
+    const int i = list0[slot];
+    const v3 o = rtx::V(s.sox[slot], s.soy[slot], s.soz[slot]);
+    const v3 nn = rtx::V(r.nx[i], r.ny[i], r.nz[i]);
+    const v3 lcol = rtx::V(light.color[0], light.color[1], light.color[2]);
+    const v3 cpos = rtx::V(cam.pos[0], cam.pos[1], cam.pos[2]);
+    const float ndl = rtx::dot(nn, ld);
+    const float diffuse = rtx::max0(ndl);
+    const v3 v = rtx::normalize(rtx::sub(cpos, o));
+    const v3 I = rtx::muls(ld, -1.0f);
+    float kk = 0.0f;
+    if (ndl > 0.0f) {
+        const v3 rr = rtx::normalize(rtx::sub(I, rtx::muls(nn, 2.0f * rtx::dot(nn, I))));
+        kk = rtx::pow30(rtx::max0(rtx::dot(v, rr)));
+    }
+    const float att = 1.0f / (0.5f * dist);
+    const v3 add = rtx::muls(rtx::muls(lcol, diffuse + kk), att);
+    s.lr[slot] = s.lr[slot] + add.x; s.lg[slot] = s.lg[slot] + add.y; s.lb[slot] = s.lb[slot] + add.z;
+    s.lit[slot] = 1;
+}
 
-    const float *tile = reinterpret_cast<const float *>(tile4);
-    const v3 cpos = rtx::V(p.cam_pos[0], p.cam_pos[1], p.cam_pos[2]);
-    unsigned long long n_cand = 0, n_pairs = 0;
-
-    for (int a = 0; a < p.num_lights; a++) {
-        const v3 lpos = rtx::V(p.lights[a].pos[0], p.lights[a].pos[1], p.lights[a].pos[2]);
-        const v3 lcol = rtx::V(p.lights[a].color[0], p.lights[a].color[1], p.lights[a].color[2]);
-        float hx[K], hy[K], hz[K], dist[K];
-        bool occ[K];
-#pragma unroll
-        for (int k = 0; k < K; k++) {
-            v3 o = rtx::V(ox[k], oy[k], oz[k]);
-            const v3 ld = rtx::normalize(rtx::sub(lpos, o));
-            const v3 o2 = rtx::add(o, rtx::muls(ld, 0.0000001f)); // shadow-ray origin
-            o = rtx::sub(o, rtx::muls(ld, 0.0000001f));           // raycol_cs.glsl:45
-            ox[k] = o.x; oy[k] = o.y; oz[k] = o.z;
-            dist[k] = rtx::distance3(lpos, o);
-            xr[0][k][tid] = o2.x; xr[1][k][tid] = o2.y; xr[2][k][tid] = o2.z;
-            xr[3][k][tid] = ld.x; xr[4][k][tid] = ld.y; xr[5][k][tid] = ld.z;
-            const v3 C = rtx::V(p.center[0], p.center[1], p.center[2]);
-            const float reach = sqrtf(rtx::dot(lpos, lpos)) + sqrtf(rtx::dot(o2, o2)) + sqrtf(rtx::dot(C, C)) +
-                                3.0f * p.radius;
-            const float sc = rtf::dir_scale(reach, ld.x, ld.y, ld.z);
-            hx[k] = ld.x * sc; hy[k] = ld.y * sc; hz[k] = ld.z * sc;
-            // `lightRay.t > d` can only hold for finite d
-            occ[k] = !valid[k] || !(dist[k] < INFINITY);
+// texture, final colour, kill rule, pixel  (raycol_cs.glsl:82-127)
+__global__ __launch_bounds__(BLOCK) void color_finish_kernel(RaySoA r, const int *__restrict__ list0,
+                                                             const int *__restrict__ count, Scratch s,
+                                                             const rt_vertex *__restrict__ verts, int num_vertices,
+                                                             const uint32_t *__restrict__ tex, int tex_w, int tex_h,
+                                                             uint32_t *__restrict__ fb)
+{
+    const int slot = blockIdx.x * BLOCK + threadIdx.x;
+    if (slot >= *count) return;
+    const int i = list0[slot];
+    v3 fin = rtx::V(0.1f, 0.1f, 0.1f);
+    if (s.lit[slot]) {
+        const int id = r.id[i];
+        v3 pa = rtx::V(0.0f, 0.0f, 0.0f), pb = pa, pc = pa;
+        float ta0 = 0.0f, ta1 = 0.0f, tb0 = 0.0f, tb1 = 0.0f, tc0 = 0.0f, tc1 = 0.0f;
+        // robust buffer access: an index outside the buffer reads zeros
+        const long long i0 = (long long)id * 3;
+        if (i0 >= 0 && i0 < num_vertices) { const rt_vertex vv = verts[i0]; pa = rtx::V(vv.pos[0], vv.pos[1], vv.pos[2]); ta0 = vv.texCoord[0]; ta1 = vv.texCoord[1]; }
+        if (i0 + 1 >= 0 && i0 + 1 < num_vertices) { const rt_vertex vv = verts[i0 + 1]; pb = rtx::V(vv.pos[0], vv.pos[1], vv.pos[2]); tb0 = vv.texCoord[0]; tb1 = vv.texCoord[1]; }
+        if (i0 + 2 >= 0 && i0 + 2 < num_vertices) { const rt_vertex vv = verts[i0 + 2]; pc = rtx::V(vv.pos[0], vv.pos[1], vv.pos[2]); tc0 = vv.texCoord[0]; tc1 = vv.texCoord[1]; }
+        const v3 o = rtx::V(s.sox[slot], s.soy[slot], s.soz[slot]);
+        const v3 v0 = rtx::sub(pb, pa), v1 = rtx::sub(pc, pa), v2 = rtx::sub(o, pa);
+        const float d00 = rtx::dot(v0, v0), d01 = rtx::dot(v0, v1), d11 = rtx::dot(v1, v1);
+        const float d20 = rtx::dot(v2, v0), d21 = rtx::dot(v2, v1);
+        const float denom = d00 * d11 - d01 * d01;
+        const float bv = (d11 * d20 - d01 * d21) / denom;
+        const float bw = (d00 * d21 - d01 * d20) / denom;
+        const float bu = 1.0f - bv - bw;
+        const float uvx = bu * ta0 + bv * tb0 + bw * tc0;
+        const float uvy = bu * ta1 + bv * tb1 + bw * tc1;
+        const float fx = uvx * (float)tex_w, fy = uvy * (float)tex_h;
+        v3 texc = rtx::V(0.0f, 0.0f, 0.0f);
+        if (tex && fx > -1.0f && fx < (float)tex_w && fy > -1.0f && fy < (float)tex_h) {
+            const uint32_t tx = tex[(size_t)((int)fy) * tex_w + (int)fx];
+            texc = rtx::V((float)(tx & 255u) / 255.0f, (float)((tx >> 8) & 255u) / 255.0f,
+                          (float)((tx >> 16) & 255u) / 255.0f);
         }
-
-        const rtf::TriRec *recs = p.light_recs + (size_t)a * p.rec_stride;
-        for (int tile_base = 0; tile_base < p.num_tris; tile_base += TILE) {
-            bool all_occ = true;
-#pragma unroll
-            for (int k = 0; k < K; k++) all_occ = all_occ && occ[k];
-            // barrier + early exit: leave when every ray of the workgroup is occluded
-            if (__syncthreads_and(all_occ ? 1 : 0)) break;
-            load_tile(tile4, recs, tile_base, p.num_tris, tid);
-            __syncthreads();
-            const int cnt = min(TILE, p.num_tris - tile_base);
-            n_pairs += (unsigned long long)cnt;
-            for (int j = 0; j < cnt; j++) {
-                const float *rec = tile + j * REC_FLOATS;
-                float g[K];
-                float G = -INFINITY;
-#pragma unroll
-                for (int k = 0; k < K; k++) {
-                    g[k] = rtf::filter_origin(rec, hx[k], hy[k], hz[k]);
-                    G = fmaxf(G, g[k]);
-                }
-                const bool any_pass = EXACT ? true : (G >= -1.0f);
-                if (__any(any_pass)) {
-                    const int tri = tile_base + j;
-                    const v3 X = vpos(p.verts, 3 * tri), Y = vpos(p.verts, 3 * tri + 1),
-                             Z = vpos(p.verts, 3 * tri + 2);
-#pragma unroll
-                    for (int k = 0; k < K; k++) {
-                        const bool pass = EXACT ? valid[k] : (g[k] >= -1.0f);
-                        if (!EXACT) n_cand += __popcll(__ballot(pass));
-                        if (pass && !occ[k]) {
-                            const v3 o = rtx::V(xr[0][k][tid], xr[1][k][tid], xr[2][k][tid]);
-                            const v3 d = rtx::V(xr[3][k][tid], xr[4][k][tid], xr[5][k][tid]);
-                            float t;
-                            if (rtx::ray_vs_triangle(o, d, X, Y, Z, t)) {
-                                if (t > 0.0f && t <= dist[k]) occ[k] = true;
-                            }
-                        }
-                    }
-                }
-            }
-        }
-
-        // spheres, then Phong for the lights that are visible (raycol_cs.glsl:50-79)
-#pragma unroll
-        for (int k = 0; k < K; k++) {
-            if (!valid[k]) continue;
-            const v3 o2 = rtx::V(xr[0][k][tid], xr[1][k][tid], xr[2][k][tid]);
-            const v3 ld = rtx::V(xr[3][k][tid], xr[4][k][tid], xr[5][k][tid]);
-            if (!occ[k]) {
-#pragma unroll
-                for (int s = 0; s < 2; s++) {
-                    float ts;
-                    if (rtx::ray_sphere(o2, ld, rtx::sphere_center(s), rtx::sphere_radius(s), ts))
-                        if (ts > 0.0f && ts <= dist[k]) occ[k] = true;
-                }
-            }
-            if (!occ[k]) {
-                lit[k] = true;
-                const v3 o = rtx::V(ox[k], oy[k], oz[k]);
-                const v3 nn = rtx::V(nx[k], ny[k], nz[k]);
-                const float ndl = rtx::dot(nn, ld);
-                const float diffuse = rtx::max0(ndl);
-                const v3 v = rtx::normalize(rtx::sub(cpos, o));
-                const v3 I = rtx::muls(ld, -1.0f);
-                float kk = 0.0f;
-                if (ndl > 0.0f) {
-                    const v3 rr = rtx::normalize(rtx::sub(I, rtx::muls(nn, 2.0f * rtx::dot(nn, I))));
-                    kk = rtx::pow30(rtx::max0(rtx::dot(v, rr)));
-                }
-                const float att = 1.0f / (0.5f * dist[k]);
-                const v3 add = rtx::muls(rtx::muls(lcol, diffuse + kk), att);
-                lr[k] = lr[k] + add.x; lg[k] = lg[k] + add.y; lb[k] = lb[k] + add.z;
-            }
+        fin = rtx::add(texc, rtx::muls(rtx::V(s.lr[slot], s.lg[slot], s.lb[slot]), 0.3f));
+        if (id + 3 * 5 - 2 < num_vertices / 3) {
+            r.id[i] = -2;
+            r.ox[i] = o.x; r.oy[i] = o.y; r.oz[i] = o.z;
         }
     }
-
-    if ((tid & 63) == 0) add_counter(p.counters, C_SH_CAND, n_cand);
-    if (tid == 0) {
-        add_counter(p.counters, C_SH_RAYS, (unsigned long long)mine * (unsigned long long)p.num_lights);
-        add_counter(p.counters, C_SH_PAIRS, n_pairs * (unsigned long long)mine);
-    }
-
-    // texture, final colour, kill rule, pixel  (raycol_cs.glsl:82-127)
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-        if (!valid[k]) continue;
-        const int i = ridx[k];
-        v3 fin = rtx::V(0.1f, 0.1f, 0.1f);
-        if (lit[k]) {
-            const int id = p.rays.id[i];
-            v3 pa = rtx::V(0.0f, 0.0f, 0.0f), pb = pa, pc = pa;
-            float ta0 = 0.0f, ta1 = 0.0f, tb0 = 0.0f, tb1 = 0.0f, tc0 = 0.0f, tc1 = 0.0f;
-            // robust buffer access: an index outside the buffer reads zeros
-            const long long i0 = (long long)id * 3;
-            if (i0 >= 0 && i0 < p.num_vertices) { const rt_vertex vv = p.verts[i0]; pa = rtx::V(vv.pos[0], vv.pos[1], vv.pos[2]); ta0 = vv.texCoord[0]; ta1 = vv.texCoord[1]; }
-            if (i0 + 1 >= 0 && i0 + 1 < p.num_vertices) { const rt_vertex vv = p.verts[i0 + 1]; pb = rtx::V(vv.pos[0], vv.pos[1], vv.pos[2]); tb0 = vv.texCoord[0]; tb1 = vv.texCoord[1]; }
-            if (i0 + 2 >= 0 && i0 + 2 < p.num_vertices) { const rt_vertex vv = p.verts[i0 + 2]; pc = rtx::V(vv.pos[0], vv.pos[1], vv.pos[2]); tc0 = vv.texCoord[0]; tc1 = vv.texCoord[1]; }
-            const v3 o = rtx::V(ox[k], oy[k], oz[k]);
-            const v3 v0 = rtx::sub(pb, pa), v1 = rtx::sub(pc, pa), v2 = rtx::sub(o, pa);
-            const float d00 = rtx::dot(v0, v0), d01 = rtx::dot(v0, v1), d11 = rtx::dot(v1, v1);
-            const float d20 = rtx::dot(v2, v0), d21 = rtx::dot(v2, v1);
-            const float denom = d00 * d11 - d01 * d01;
-            const float bv = (d11 * d20 - d01 * d21) / denom;
-            const float bw = (d00 * d21 - d01 * d20) / denom;
-            const float bu = 1.0f - bv - bw;
-            const float uvx = bu * ta0 + bv * tb0 + bw * tc0;
-            const float uvy = bu * ta1 + bv * tb1 + bw * tc1;
-            const float fx = uvx * (float)p.tex_w, fy = uvy * (float)p.tex_h;
-            v3 texc = rtx::V(0.0f, 0.0f, 0.0f);
-            if (p.tex && fx > -1.0f && fx < (float)p.tex_w && fy > -1.0f && fy < (float)p.tex_h) {
-                const uint32_t tx = p.tex[(size_t)((int)fy) * p.tex_w + (int)fx];
-                texc = rtx::V((float)(tx & 255u) / 255.0f, (float)((tx >> 8) & 255u) / 255.0f,
-                              (float)((tx >> 16) & 255u) / 255.0f);
-            }
-            fin = rtx::add(texc, rtx::muls(rtx::V(lr[k], lg[k], lb[k]), 0.3f));
-            if (id + 3 * 5 - 2 < p.num_vertices / 3) {
-                p.rays.id[i] = -2;
-                p.rays.ox[i] = ox[k]; p.rays.oy[i] = oy[k]; p.rays.oz[i] = oz[k];
-            }
-        }
-        p.fb[i] = rtx::to_unorm8(fin.x) | (rtx::to_unorm8(fin.y) << 8) | (rtx::to_unorm8(fin.z) << 16) | 0xff000000u;
-    }
+    fb[i] = rtx::to_unorm8(fin.x) | (rtx::to_unorm8(fin.y) << 8) | (rtx::to_unorm8(fin.z) << 16) | 0xff000000u;
 }
 
 } // namespace rtk

@@ -140,14 +140,14 @@ class RayTracer:
         c = (C.c_uint64 * 8)()
         self._chk(self._lib.rt_get_counters(self._ctx, c))
         names = ["closest_rays", "shadow_rays", "closest_pairs", "shadow_pairs",
-                 "closest_candidates", "shadow_candidates"]
+                 "closest_candidates", "shadow_candidates", "closest_slow_steps", "shadow_slow_steps"]
         return {n: int(c[i]) for i, n in enumerate(names)}
 
     def kernel_log(self):
         """Per-launch records of the traversal kernels since the last call (structured array)."""
-        out = np.zeros(256, dtype=_native.KERNEL_RECORD_DTYPE)
+        out = np.zeros(1024, dtype=_native.KERNEL_RECORD_DTYPE)
         n = C.c_int(0)
-        self._chk(self._lib.rt_kernel_log(self._ctx, out.ctypes.data, 256, C.byref(n)))
+        self._chk(self._lib.rt_kernel_log(self._ctx, out.ctypes.data, 1024, C.byref(n)))
         return out[:n.value].copy()
 
     # -- interop --------------------------------------------------------------

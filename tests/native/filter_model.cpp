@@ -57,7 +57,7 @@ extern "C" void fm_check_origin(int n_tris, const float *verts, int n_rays, cons
         rtf::make_origin_rec(X, Y, Z, O, &rec);
         for (int i = 0; i < n_rays; i++) {
             const float *o = org + 3 * i, *d = dir + 3 * i;
-            float reach = norm3(O) + norm3(o) + norm3(center) + 3.0f * radius;
+            float reach = rtf::reach_shared(O, o, center, radius);
             float sc = rtf::dir_scale(reach, d[0], d[1], d[2]);
             float g = rtf::filter_origin(rec.v, d[0] * sc, d[1] * sc, d[2] * sc);
             bool p = g >= -1.0f;
@@ -70,4 +70,53 @@ extern "C" void fm_check_origin(int n_tris, const float *verts, int n_rays, cons
         }
     }
     stats[0] = pairs; stats[1] = pass; stats[2] = acc; stats[3] = bad;
+}
+
+// Cone pre-filter + edge filter cascade of the shared-origin traversal, as the kernel
+// evaluates it.  tmax may be null (closest hit: any t > 0 counts) or hold one limit per ray
+// (shadow query: 0 < t <= tmax).  sign = +1 camera rays, -1 shadow rays.
+// stats: [0] pairs [1] cone passes [2] cone+edge passes [3] oracle accepts [4] violations
+//        [5] triangles whose cone is "always pass" [6] rays outside the cones' validity (wild)
+extern "C" void fm_check_cone(int n_tris, const float *verts, int n_rays, const float *O, const float *org,
+                              const float *dir, const float *tmax, const float *center, float radius, float sign,
+                              long long *stats)
+{
+    long long pairs = 0, p1 = 0, p2 = 0, acc = 0, bad = 0, always = 0, wildn = 0;
+    const double extent = rtf::scene_extent(O, center, radius);
+    const double rmax = rtf::cone_reach_max(O, center, radius);
+    const float rmaxf = (float)rmax;
+#pragma omp parallel for reduction(+ : pairs, p1, p2, acc, bad, always, wildn) schedule(static)
+    for (int k = 0; k < n_tris; k++) {
+        const float *X = verts + 9 * k, *Y = X + 3, *Z = X + 6;
+        rtf::TriRec rec;
+        rtf::make_origin_rec(X, Y, Z, O, &rec);
+        rtf::ConeRec cone;
+        rtf::make_cone_rec(X, Y, Z, O, &rec, extent, rmax, &cone);
+        always += (cone.v[3] == -2.0f);
+        for (int i = 0; i < n_rays; i++) {
+            const float *o = org + 3 * i, *d = dir + 3 * i;
+            const float reach = rtf::reach_shared(O, o, center, radius);
+            const float inv = sign / sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+            const float bx = d[0] * inv, by = d[1] * inv, bz = d[2] * inv;
+            const float g = rtf::dir_scale(reach, bx, by, bz);
+            const bool wild = !(reach <= rmaxf);
+            const float dt = fmaf(cone.v[2], bz, fmaf(cone.v[1], by, cone.v[0] * bx));
+            const bool c1 = (dt >= cone.v[3]) || wild;
+            bool c2 = false;
+            if (c1) {
+                const float s = sign * g;
+                c2 = rtf::filter_origin(rec.v, bx * s, by * s, bz * s) >= -1.0f;
+            }
+            float t;
+            bool a = rto_ray_vs_triangle(o, d, X, Y, Z, &t) != 0 && t > 0.0f;
+            if (a && tmax) a = t <= tmax[i];
+            pairs++;
+            p1 += c1;
+            p2 += c2;
+            acc += a;
+            bad += (a && !c2);
+            if (k == 0) wildn += wild;
+        }
+    }
+    stats[0] = pairs; stats[1] = p1; stats[2] = p2; stats[3] = acc; stats[4] = bad; stats[5] = always; stats[6] = wildn;
 }

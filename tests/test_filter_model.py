@@ -20,6 +20,7 @@ def fm():
     P = C.c_void_p
     lib.fm_check_general.argtypes = [C.c_int, P, C.c_int, P, P, P, C.c_float, P]
     lib.fm_check_origin.argtypes = [C.c_int, P, C.c_int, P, P, P, P, C.c_float, P]
+    lib.fm_check_cone.argtypes = [C.c_int, P, C.c_int, P, P, P, P, P, C.c_float, C.c_float, P]
     return lib
 
 
@@ -201,3 +202,130 @@ def test_degenerate_and_nonfinite_inputs_never_pass_wrongly(fm):
     O = f32([0.1, 0.2, -3.0])
     pairs, passed, acc, bad = run_origin(fm, tris, O, (O[None, :] + dirs * f32(0.001)).astype(f32), dirs)
     assert bad == 0
+
+
+# -- cone pre-filter (level 1 of the shared-origin traversal) -------------------------------
+def run_cone(fm, tris, O, org, dirs, sign, tmax=None):
+    c, r = bounding_sphere(tris)
+    stats = (C.c_longlong * 7)()
+    tris = np.ascontiguousarray(tris, dtype=f32)
+    O = np.ascontiguousarray(O, dtype=f32)
+    org = np.ascontiguousarray(org, dtype=f32)
+    dirs = np.ascontiguousarray(dirs, dtype=f32)
+    tm = None if tmax is None else np.ascontiguousarray(tmax, dtype=f32)
+    fm.fm_check_cone(tris.shape[0], tris.ctypes.data, org.shape[0], O.ctypes.data, org.ctypes.data,
+                     dirs.ctypes.data, tm.ctypes.data if tm is not None else None, c.ctypes.data, r, sign, stats)
+    return dict(zip(["pairs", "cone", "both", "accepts", "bad", "always", "wild"], list(stats)))
+
+
+@pytest.mark.parametrize("sc", SCENES, ids=[s["name"] for s in SCENES])
+def test_cone_cascade_primary_rays(fm, sc):
+    rs = np.random.RandomState(51)
+    tris = tris_random(rs, 1500, sc["extent"], sc["size"], sc["offset"])
+    for trial in range(3):
+        O = (rs.uniform(-3, 3, 3) * sc["extent"] + np.asarray(sc["offset"])).astype(f32)
+        _, dirs = rays_through_features(rs, tris, O[None, :].astype(np.float64))
+        org = (O[None, :] + dirs * f32(0.001)).astype(f32)
+        st = run_cone(fm, tris, O, org, dirs, 1.0)
+        assert st["bad"] == 0, st
+        assert st["accepts"] > 1000
+        assert st["wild"] == 0
+        assert st["always"] < 0.05 * tris.shape[0], st    # the cone is the norm, not the exception
+        # and it rejects almost everything (rays here are all aimed at triangle features;
+        # triangles as large as the scene, or float32 coordinates ~1000x the scene size, widen it)
+        limit = {"big_tris": 0.6, "far_from_world_origin": 0.3}.get(sc["name"], 0.05)
+        assert st["cone"] < limit * st["pairs"], st
+
+
+def test_cone_cascade_origin_inside_the_scene_and_nasty_triangles(fm):
+    rs = np.random.RandomState(52)
+    tris = tris_nasty(rs, 3000, 2.0)
+    for O in ([0.1, -0.2, 0.3], [0.0, 0.0, 0.0], [5.0, 1.0, -2.0]):
+        O = f32(O)
+        _, dirs = rays_through_features(rs, tris, O[None, :].astype(np.float64))
+        org = (O[None, :] + dirs * f32(0.001)).astype(f32)
+        st = run_cone(fm, tris, O, org, dirs, 1.0)
+        assert st["bad"] == 0 and st["accepts"] > 1000, st
+
+
+def test_cone_cascade_origin_on_triangle_planes(fm):
+    """The camera lies exactly in the plane of many triangles (a floor it stands on), on an edge
+    line of some and at a vertex of one: those cones must fall back to 'always pass'."""
+    rs = np.random.RandomState(53)
+    n = 400
+    xy = rs.uniform(-2, 2, (n, 3, 2))
+    floor = np.concatenate([xy, np.zeros((n, 3, 1))], axis=2).astype(f32)     # all in z = 0
+    O = f32([0.25, -0.5, 0.0])
+    floor[0, 0] = O                                                               # a vertex at the origin
+    floor[1, 0] = O + f32([1, 0, 0]); floor[1, 1] = O - f32([1, 0, 0])            # origin on an edge
+    other = tris_random(rs, 600, 1.5, 0.3)
+    tris = np.concatenate([floor, other])
+    _, dirs = rays_through_features(rs, tris, O[None, :].astype(np.float64))
+    org = (O[None, :] + dirs * f32(0.001)).astype(f32)
+    st = run_cone(fm, tris, O, org, dirs, 1.0)
+    assert st["bad"] == 0, st
+    assert st["always"] >= n
+
+
+@pytest.mark.parametrize("sc", SCENES[:3], ids=[s["name"] for s in SCENES[:3]])
+def test_cone_cascade_shadow_rays(fm, sc):
+    rs = np.random.RandomState(54)
+    tris = tris_random(rs, 1500, sc["extent"], sc["size"], sc["offset"])
+    L = (rs.uniform(-3, 3, 3) * sc["extent"] + np.asarray(sc["offset"])).astype(f32)
+    _, dirs = rays_through_features(rs, tris, L[None, :].astype(np.float64))
+    # surface points behind the aimed-at feature, at a random distance from the light; half of
+    # them barely behind it (the occluder sits right at the ray's start) or barely in front
+    dist = rs.uniform(0.05, 5.0, (dirs.shape[0], 1)) * sc["extent"]
+    p = (L[None, :].astype(np.float64) + dirs.astype(np.float64) * dist).astype(f32)
+    dlt = (L[None, :] - p).astype(f32)
+    inv = (f32(1.0) / np.sqrt((dlt * dlt).sum(1, dtype=f32))).astype(f32)
+    ld = (dlt * inv[:, None]).astype(f32)
+    org = (p + ld * f32(0.0000001)).astype(f32)
+    pm = (p - ld * f32(0.0000001)).astype(f32)
+    tmax = np.sqrt(((L[None, :] - pm) ** 2).sum(1, dtype=f32)).astype(f32)
+    st = run_cone(fm, tris, L, org, ld, -1.0, tmax)
+    assert st["bad"] == 0, st
+    assert st["accepts"] > 300, st
+    limit = {"big_tris": 0.6, "far_from_world_origin": 0.3}.get(sc["name"], 0.05)
+    assert st["cone"] < limit * st["pairs"], st
+
+
+def test_cone_cascade_shadow_rays_light_near_surfaces(fm):
+    """Occluders hugging the light: triangles whose plane passes within rounding of the light."""
+    rs = np.random.RandomState(55)
+    L = f32([0.3, 0.1, -0.2])
+    tris = tris_random(rs, 800, 1.0, 0.3)
+    for i in range(200):   # planes through (or a hair off) the light
+        a, b = rs.normal(size=3), rs.normal(size=3)
+        off = rs.normal(size=3) * 10.0 ** rs.uniform(-9, -4)
+        c = rs.uniform(-1, 1, 2)
+        tris[i] = (L + off + np.array([c[0] * a + c[1] * b + 0.3 * rs.normal() * a,
+                                       c[0] * a + c[1] * b + 0.3 * rs.normal() * b,
+                                       c[0] * a + c[1] * b - 0.3 * rs.normal() * (a + b)])).astype(f32)
+    _, dirs = rays_through_features(rs, tris, L[None, :].astype(np.float64))
+    dist = rs.uniform(0.05, 3.0, (dirs.shape[0], 1))
+    p = (L[None, :].astype(np.float64) + dirs.astype(np.float64) * dist).astype(f32)
+    dlt = (L[None, :] - p).astype(f32)
+    inv = (f32(1.0) / np.sqrt((dlt * dlt).sum(1, dtype=f32))).astype(f32)
+    ld = (dlt * inv[:, None]).astype(f32)
+    org = (p + ld * f32(0.0000001)).astype(f32)
+    pm = (p - ld * f32(0.0000001)).astype(f32)
+    tmax = np.sqrt(((L[None, :] - pm) ** 2).sum(1, dtype=f32)).astype(f32)
+    st = run_cone(fm, tris, L, org, ld, -1.0, tmax)
+    assert st["bad"] == 0, st
+
+
+def test_cone_cascade_wild_rays_fall_back_to_the_edge_filter(fm):
+    """Shadow rays that start far outside the scene bound are outside the cones' validity."""
+    rs = np.random.RandomState(56)
+    tris = tris_random(rs, 500, 1.0, 0.2)
+    L = f32([0.5, 2.0, -1.0])
+    _, dirs = rays_through_features(rs, tris, L[None, :].astype(np.float64), per_tri=3)
+    p = (L[None, :].astype(np.float64) + dirs.astype(np.float64) * 500.0).astype(f32)
+    dlt = (L[None, :] - p).astype(f32)
+    inv = (f32(1.0) / np.sqrt((dlt * dlt).sum(1, dtype=f32))).astype(f32)
+    ld = (dlt * inv[:, None]).astype(f32)
+    org = (p + ld * f32(0.0000001)).astype(f32)
+    st = run_cone(fm, tris, L, org, ld, -1.0, np.full(ld.shape[0], 1e9, dtype=f32))
+    assert st["bad"] == 0, st
+    assert st["wild"] == ld.shape[0]
