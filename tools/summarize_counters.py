@@ -1,0 +1,50 @@
+"""Summarises the rocprofv3 outputs of tools/prof_counters.sh into one text file.
+usage: python tools/summarize_counters.py gpurun_out/prof_<tag> profiles/<name>.txt"""
+import collections
+import csv
+import sys
+
+base, out = sys.argv[1], sys.argv[2]
+
+
+def short(n):
+    return n.split("(")[0].replace("void ", "")
+
+
+lines = []
+stats = list(csv.DictReader(open(f"{base}/trace/t_kernel_stats.csv")))
+lines.append("== rocprofv3 --kernel-trace --stats (python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline) ==")
+lines.append(f"{'kernel':70s} {'calls':>6s} {'avg_us':>12s} {'total_ms':>10s} {'%':>6s}")
+for r in stats[:14]:
+    lines.append(f"{short(r['Name'])[:70]:70s} {r['Calls']:>6s} {float(r['AverageNs'])/1e3:12.1f} "
+                 f"{float(r['TotalDurationNs'])/1e6:10.2f} {float(r['Percentage']):6.2f}")
+dur = {short(r["Name"]): (float(r["AverageNs"]) * 1e-9, int(r["Calls"])) for r in stats}
+
+agg = collections.defaultdict(lambda: collections.defaultdict(float))
+calls = collections.defaultdict(set)
+for f in ("pmc_sq/sq", "pmc_fetch/f", "pmc_write/w", "pmc_misc/m"):
+    for r in csv.DictReader(open(f"{base}/{f}_counter_collection.csv")):
+        k = short(r["Kernel_Name"])
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        calls[(k, f)].add(r["Dispatch_Id"])
+lines.append("")
+lines.append("== hardware counters, per launch (each --pmc set collected in a run of its own) ==")
+for k, v in agg.items():
+    if not any(s in k for s in ("traverse", "raygen", "finish", "setup")):
+        continue
+    n = max(len(calls[(k, f)]) for f in ("pmc_sq/sq", "pmc_fetch/f", "pmc_write/w", "pmc_misc/m"))
+    t, _ = dur.get(k, (float("nan"), 0))
+    lines.append(f"{k}   launches={n}  avg duration {t*1e3:.3f} ms")
+    per = {a: b / n for a, b in v.items()}
+    valu = per.get("SQ_INSTS_VALU", 0.0)
+    lines.append(f"   SQ_INSTS_VALU {valu:.4g}  SQ_INSTS_SALU {per.get('SQ_INSTS_SALU',0):.4g}  SQ_INSTS_LDS {per.get('SQ_INSTS_LDS',0):.4g}"
+                 f"  SQ_WAVES {per.get('SQ_WAVES',0):.4g}  SQ_INSTS_VALU_MFMA_F32 {per.get('SQ_INSTS_VALU_MFMA_F32',0):.4g}")
+    clk = per.get("GRBM_GUI_ACTIVE", 0.0) / 8.0 / t if t == t and t > 0 else float("nan")
+    lines.append(f"   VALU wave-instructions/s {valu/t/1e9:.1f} G   effective clock (GRBM_GUI_ACTIVE/8/t) {clk/1e9:.2f} GHz"
+                 f"   VALU issue utilisation {valu/t/(1024*0.5*clk)*100 if clk==clk and clk>0 else float('nan'):.1f} % of 1024 SIMDs x 0.5 inst/clk")
+    # FETCH_SIZE / WRITE_SIZE are reported in KiB; FETCH_SIZE counts 128-B reads as 64 B on gfx950 (x2)
+    lines.append(f"   FETCH_SIZE {per.get('FETCH_SIZE',0)*1024/1e6:.1f} MB raw (x2 for wide coalesced reads on gfx950 = {per.get('FETCH_SIZE',0)*2048/1e6:.1f} MB)"
+                 f"   WRITE_SIZE {per.get('WRITE_SIZE',0)*1024/1e6:.1f} MB   -> {(per.get('FETCH_SIZE',0)*2048+per.get('WRITE_SIZE',0)*1024)/t/1e12:.3f} TB/s HBM")
+    lines.append(f"   SQ_LDS_IDX_ACTIVE {per.get('SQ_LDS_IDX_ACTIVE',0):.4g}  SQ_LDS_BANK_CONFLICT {per.get('SQ_LDS_BANK_CONFLICT',0):.4g}")
+open(out, "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))
