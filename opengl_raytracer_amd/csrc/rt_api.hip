@@ -36,6 +36,7 @@ struct rt_ctx {
     int n_rays = 0;
     std::vector<int32_t> row_map_h;
     int *row_map_d = nullptr;
+    int *perm_d = nullptr; // local ray indices in pixel-tile order
 
     rt_vertex *verts = nullptr;
     int num_vertices = 0, num_tris = 0;
@@ -141,8 +142,27 @@ static void setup_planes(rt_ctx *c)
     c->rays.nx = b + 11 * s; c->rays.ny = b + 12 * s; c->rays.nz = b + 13 * s;
 }
 
+// Enumerates the local pixels (x, local row) in 8x8 tiles, the tiles of a 32x32 block in
+// Morton order, blocks row-major: 64 consecutive entries are one tile, 256 a 16x16 square.
+static void build_tile_order(int width, int rows, std::vector<int32_t> &perm)
+{
+    perm.clear();
+    perm.reserve((size_t)width * rows);
+    for (int by = 0; by < rows; by += 32)
+        for (int bx = 0; bx < width; bx += 32)
+            for (int m = 0; m < 16; m++) {
+                const int tx = bx + 8 * ((m & 1) | ((m >> 1) & 2)), ty = by + 8 * (((m >> 1) & 1) | ((m >> 2) & 2));
+                if (tx >= width || ty >= rows) continue;
+                for (int yy = ty; yy < ty + 8 && yy < rows; yy++)
+                    for (int xx = tx; xx < tx + 8 && xx < width; xx++) perm.push_back(yy * width + xx);
+            }
+}
+
 static int upload_row_map(rt_ctx *c)
 {
+    std::vector<int32_t> perm;
+    build_tile_order(c->width, c->local_rows, perm);
+    HIPCHK(c, hipMemcpyAsync(c->perm_d, perm.data(), perm.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->row_map_d, c->row_map_h.data(), c->row_map_h.size() * sizeof(int32_t),
                              hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -190,6 +210,7 @@ extern "C" int rt_create(rt_ctx **out, int hip_device, int width, int height)
     CRCHK(hipMemsetAsync(c->planes, 0, 14 * c->stride * sizeof(float), c->stream));
     setup_planes(c);
     CRCHK(hipMalloc(&c->row_map_d, (size_t)height * sizeof(int)));
+    CRCHK(hipMalloc(&c->perm_d, c->cap * sizeof(int)));
     CRCHK(hipMalloc(&c->list, c->cap * sizeof(int)));
     CRCHK(hipMalloc(&c->alist[0], c->cap * sizeof(int)));
     CRCHK(hipMalloc(&c->alist[1], c->cap * sizeof(int)));
@@ -227,9 +248,11 @@ extern "C" int rt_create(rt_ctx **out, int hip_device, int width, int height)
     c->n_rays = width * height;
     c->row_map_h.resize(height);
     for (int y = 0; y < height; y++) c->row_map_h[y] = y;
-    CRCHK(hipMemcpyAsync(c->row_map_d, c->row_map_h.data(), (size_t)height * sizeof(int), hipMemcpyHostToDevice,
-                         c->stream));
-    CRCHK(hipStreamSynchronize(c->stream));
+    if (upload_row_map(c) != RT_OK) {
+        g_create_error = c->error;
+        rt_destroy(c);
+        return RT_ERR_HIP;
+    }
 #undef CRCHK
     *out = c;
     return RT_OK;
@@ -250,6 +273,7 @@ extern "C" void rt_destroy(rt_ctx *c)
     }
     (void)hipFree(c->planes);
     (void)hipFree(c->row_map_d);
+    (void)hipFree(c->perm_d);
     (void)hipFree(c->verts);
     (void)hipFree(c->rec_general);
     (void)hipFree(c->rec_camera);
@@ -652,13 +676,14 @@ extern "C" int rt_intersect(rt_ctx *c)
         const int *list = nullptr, *count = nullptr;
         int n_upper = c->n_rays;
         if (shared) {
-            // fresh rays: all live, all through camera_pos
+            // fresh rays: all live, all through camera_pos; visited in pixel-tile order
             if (int r = refresh_camera_recs(c)) return r;
+            list = c->perm_d;
         } else {
             HIPCHK(c, hipMemsetAsync(c->count_d, 0, sizeof(int), c->stream));
             hipLaunchKernelGGL((compact_kernel<0>), dim3(cdiv(c->n_rays, BLOCK * COMPACT_ITERS)), dim3(BLOCK), 0,
-                               c->stream, c->rays, (const int *)nullptr, (const int *)nullptr, c->n_rays,
-                               (const int *)nullptr, c->list, c->count_d, (uint32_t *)nullptr);
+                               c->stream, c->rays, (const int *)c->perm_d, (const int *)nullptr, (const int *)nullptr,
+                               c->n_rays, (const int *)nullptr, c->list, c->count_d, (uint32_t *)nullptr);
             HIPCHK(c, hipGetLastError());
             if (int r = read_count(c, 0, &n_upper)) return r;
             list = c->list;
@@ -717,8 +742,8 @@ extern "C" int rt_color(rt_ctx *c)
             if (int r = refresh_light_recs(c)) return r;
             HIPCHK(c, hipMemsetAsync(c->count_d + 1, 0, sizeof(int), c->stream));
             hipLaunchKernelGGL((compact_kernel<1>), dim3(cdiv(c->n_rays, BLOCK * COMPACT_ITERS)), dim3(BLOCK), 0,
-                               c->stream, c->rays, (const int *)nullptr, (const int *)nullptr, c->n_rays,
-                               (const int *)nullptr, c->list, c->count_d + 1, c->fb);
+                               c->stream, c->rays, (const int *)c->perm_d, (const int *)nullptr, (const int *)nullptr,
+                               c->n_rays, (const int *)nullptr, c->list, c->count_d + 1, c->fb);
             HIPCHK(c, hipGetLastError());
             int n0 = 0;
             if (int r = read_count(c, 1, &n0)) return r;
@@ -756,7 +781,7 @@ extern "C" int rt_color(rt_ctx *c)
                             int *ocount = c->count_d + 2 + pp;
                             HIPCHK(c, hipMemsetAsync(ocount, 0, sizeof(int), c->stream));
                             hipLaunchKernelGGL((compact_kernel<2>), dim3(cdiv(n0, BLOCK * COMPACT_ITERS)),
-                                               dim3(BLOCK), 0, c->stream, c->rays, alist, acount, n0,
+                                               dim3(BLOCK), 0, c->stream, c->rays, (const int *)nullptr, alist, acount, n0,
                                                (const int *)c->scratch.occ, c->alist[pp], ocount, (uint32_t *)nullptr);
                             HIPCHK(c, hipGetLastError());
                             alist = c->alist[pp];

@@ -168,6 +168,9 @@ __global__ __launch_bounds__(BLOCK) void prep_origin_kernel(const rt_vertex *__r
 // stream compaction: out[] = the entries that satisfy a predicate; workgroup
 // segments land in arbitrary order, entries keep their order inside a segment of
 // 2048.
+// Rays are visited through `perm`, the enumeration of the frame's pixels in 8x8 tiles
+// (Morton order inside 32x32 blocks), so that 64 consecutive list entries are rays through
+// neighbouring pixels: a wavefront's rays then see the same few triangles.
 //   MODE 0: ray indices i in [0,n) that are live      (primitiveID != -2)   -- before intersect
 //   MODE 1: ray indices with a finite origin                               -- before shading;
 //           the others are reference-grey (see color_finish_kernel) and get their pixel here
@@ -177,7 +180,8 @@ __global__ __launch_bounds__(BLOCK) void prep_origin_kernel(const rt_vertex *__r
 constexpr int COMPACT_ITERS = 8;
 
 template <int MODE>
-__global__ __launch_bounds__(BLOCK) void compact_kernel(RaySoA r, const int *__restrict__ in_list,
+__global__ __launch_bounds__(BLOCK) void compact_kernel(RaySoA r, const int *__restrict__ perm,
+                                                        const int *__restrict__ in_list,
                                                         const int *__restrict__ in_count, int n_fixed,
                                                         const int *__restrict__ occ, int *__restrict__ out,
                                                         int *__restrict__ out_count, uint32_t *__restrict__ fb)
@@ -197,12 +201,16 @@ __global__ __launch_bounds__(BLOCK) void compact_kernel(RaySoA r, const int *__r
         value[it] = i;
         if (i < n) {
             if (MODE == 0) {
-                p = r.id[i] != -2;
+                const int ri = perm[i]; // rays are visited in pixel-tile order
+                value[it] = ri;
+                p = r.id[ri] != -2;
             } else if (MODE == 1) {
-                float a = r.ox[i], b = r.oy[i], c = r.oz[i];
+                const int ri = perm[i];
+                value[it] = ri;
+                float a = r.ox[ri], b = r.oy[ri], c = r.oz[ri];
                 // finite <=> |x| < inf (false for NaN)
                 p = (fabsf(a) < INFINITY) && (fabsf(b) < INFINITY) && (fabsf(c) < INFINITY);
-                if (!p) fb[i] = 0xff1a1a1au; // vec3(0.1) -> 26, alpha 255
+                if (!p) fb[ri] = 0xff1a1a1au; // vec3(0.1) -> 26, alpha 255
             } else {
                 const int slot = in_list ? in_list[i] : i;
                 value[it] = slot;
@@ -427,7 +435,8 @@ __global__ __launch_bounds__(BLOCK) void traverse_kernel(TraverseParams p)
 
 #pragma unroll
     for (int k = 0; k < K; k++) {
-        const int s = s0 + k * BLOCK + tid;
+        // a wavefront takes 64 K consecutive list entries: K runs of 64 = K neighbouring pixel tiles
+        const int s = s0 + ((tid >> 6) * K + k) * 64 + (tid & 63);
         valid[k] = s < n;
         slot[k] = valid[k] ? (p.alist ? p.alist[s] : s) : 0;
         v3 o = rtx::V(qn, qn, qn), d = o;
@@ -633,7 +642,9 @@ __global__ __launch_bounds__(BLOCK) void traverse_kernel(TraverseParams p)
                             const bool in = ((t >= w) || wild[k]) && (w < 2.0f) && !occ[k];
                             const unsigned long long m = __builtin_amdgcn_ballot_w64(in);
                             if (m) {
-                                if (in) queue[qcount + lanes_below(m)] = (trel << 11) | (unsigned int)(k * BLOCK + tid);
+                                if (in)
+                                    queue[qcount + lanes_below(m)] =
+                                        (trel << 11) | (unsigned int)(((tid >> 6) * K + k) * 64 + (tid & 63));
                                 qcount += __popcll(m);
                             }
                         }
