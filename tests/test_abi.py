@@ -10,10 +10,10 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "rt.h")).read()
+def declared_symbols(header="rt.h", prefix="rt_"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(" + prefix + r"[a-z0-9_]+)\s*\(", text)))
 
 
 def test_header_declares_the_three_stage_calls():
@@ -35,6 +35,20 @@ def test_library_exports_every_declared_symbol():
     assert lib.rt_version is not None
     lib.rt_version.restype = C.c_char_p
     assert b"gfx950" in lib.rt_version()
+
+
+def test_host_library_exports_every_declared_symbol():
+    """librt_host.so (OBJ/MTL, images, camera, lights, CSV, markers) against include/rt_host.h."""
+    import subprocess
+    from opengl_raytracer_amd import host
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "opengl_raytracer_amd", "csrc", "host")])
+    lib = C.CDLL(host.LIB_PATH)
+    syms = declared_symbols("rt_host.h", "rth_")
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(lib, s), f"librt_host.so does not export {s}"
+    assert sorted(host.PROTOTYPES) == syms
+    assert C.sizeof(host.Material) == 128 + 4 + 36 + 256 + 4
 
 
 def test_record_sizes_match_the_reference_layouts():
