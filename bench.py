@@ -31,6 +31,17 @@ PEAK_FP32_TFLOPS = 157.3      # MI355X vector FP32 peak
 METRIC = "Mrays/s (primary+secondary) at 4K vs triangle count; % FP32 VALU peak"
 
 
+def asset_mesh(sub, name):
+    """Group 0 of an OBJ under assets/, through the host library's loader, as rt_set_mesh records."""
+    from opengl_raytracer_amd import host
+    return host.Mesh().LoadFromObjFile(os.path.join(ROOT, "assets", sub) + os.sep, name).packed(0)
+
+
+def asset_texture():
+    from opengl_raytracer_amd import host
+    return host.load_image(os.path.join(ROOT, "assets", "sword", "sword.png"), invert_y=True)
+
+
 def workload(name):
     from opengl_raytracer_amd import scenes
     if name == "soup64k_4k_p6":
@@ -45,18 +56,24 @@ def workload(name):
         return dict(kind="views", width=1920, height=1080, passes=1, lights=1,
                     mesh=scenes.triangle_soup(262144, seed=12346), tex=scenes.noise_texture(256, 256), cams=cams,
                     desc="synthetic soup, 262144 triangles (seed 12346), 64 views of 1920x1080, 1 pass, 1 light")
-    if name == "blob28k_1080p_p1":
-        return dict(kind="tiles", width=1920, height=1080, passes=1, lights=1, mesh=scenes.blob(),
-                    tex=scenes.noise_texture(256, 256), cams=[scenes.look_at_camera((0.4, 0.3, -1.8), (0, 0, 0))],
-                    desc="28576-triangle closed blob (stand-in for the absent bunny.obj), 1920x1080, 1 pass, 1 light")
-    if name == "blobsword_4k_p4":
-        sword = scenes.quad_grid(11, 7, origin=(-0.1, -1.2, -1.0), du=(0.2, 0.0, 0.05), dv=(0.0, 2.4, 0.1))
-        sword = np.concatenate([sword, sword[:33]])  # 154 + 11 = 165 triangles, like sword_fixed
-        return dict(kind="tiles", width=3840, height=2160, passes=4, lights=1,
-                    mesh=scenes.concat_meshes(scenes.blob(), sword), tex=scenes.noise_texture(1024, 1024),
-                    cams=[scenes.look_at_camera((0.4, 0.3, -1.8), (0, 0, 0))],
-                    desc="28576-triangle blob + 165-triangle blade (stand-ins for bunny + sword), 3840x2160, "
-                         "4 passes (3 bounces), 1 light, 1024x1024 texture")
+    if name == "sword_800_p2":
+        # the scene, camera and window RunRaytracer sets up (main.cpp:393, 402-414, 607), one bounce
+        return dict(kind="tiles", width=800, height=800, passes=2, lights=1, mesh=asset_mesh("sword", "sword_fixed.obj"),
+                    tex=asset_texture(), cams=[scenes.default_camera()], data="reference scene (mesh rebuilt from sword_fixed.blend)",
+                    desc="sword_fixed.obj (165 triangles) with sword.png, the reference's camera, 800x800, "
+                         "2 passes (1 bounce), 1 light")
+    if name == "bunny_1080p_p1":
+        mesh = asset_mesh("bunny", "bunny.obj")
+        return dict(kind="tiles", width=1920, height=1080, passes=1, lights=1, mesh=mesh, tex=scenes.checker_texture(64, 64, 8),
+                    cams=[scenes.look_at_camera((0.8, 1.5, -1.9), (0.0, 1.0, -0.3))],
+                    data="reference scene (mesh rebuilt from bunny.blend)",
+                    desc="bunny.obj (28576 triangles), 1920x1080, 1 pass (primary + shadow rays), 1 light")
+    if name == "swordbunny_4k_p4":
+        mesh = scenes.concat_meshes(asset_mesh("sword", "sword_fixed.obj"), asset_mesh("bunny", "bunny.obj"))
+        return dict(kind="tiles", width=3840, height=2160, passes=4, lights=1, mesh=mesh, tex=asset_texture(),
+                    cams=[scenes.default_camera()], data="reference scenes (meshes rebuilt from the .blend sources)",
+                    desc="sword_fixed.obj + bunny.obj (165 + 28576 triangles) with sword.png, the reference's camera, "
+                         "3840x2160, 4 passes (3 bounces), 1 light")
     raise SystemExit(f"unknown workload {name}")
 
 
@@ -203,7 +220,7 @@ def main():
             "metric": METRIC, "value": rays / dt / 1e6, "unit": "Mrays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
+            "data": wl.get("data", "synthetic"),
             "config": {"workload": args.workload, "description": wl["desc"], "width": wl["width"],
                        "height": wl["height"], "views": len(wl["cams"]), "triangles": int(wl["mesh"].shape[0] // 3),
                        "passes": wl["passes"], "lights": wl["lights"], "sharding": shard_desc,
