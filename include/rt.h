@@ -175,7 +175,7 @@ int rt_stage_ms(rt_ctx *ctx, float ms[3]);
 int rt_get_counters(rt_ctx *ctx, uint64_t counters[8]);
 
 /* One record per traversal-kernel launch made by rt_intersect / rt_color since
- * the last rt_kernel_log / rt_create (at most the 256 most recent launches).
+ * the last rt_kernel_log / rt_create (at most the 1024 most recent launches).
  *   stage : 1 = closest-hit traversal (rt_intersect), 2 = shadow traversal + shading (rt_color)
  *   form  : 0 = filter for arbitrary rays, 1 = filter for rays sharing an origin
  *   rays_per_lane : 1, 2 or 4
