@@ -121,7 +121,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="soup64k_4k_p6")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--trace-mode", type=int, default=0)
+    ap.add_argument("--trace-mode", type=int, default=2, help="0 filtered, 1 exact, 2 clustered (default)")
     args = ap.parse_args()
 
     import torch
@@ -203,7 +203,7 @@ def main():
                 share = a["pairs"] / max(sum(x["pairs"] for kk, x in groups.items() if kk[0] == 2), 1.0)
                 pairs = cnt["shadow_pairs"] * share
             name = ("closest_hit_kernel" if stage == 1 else "shade_kernel") + \
-                   f"<K={k},{'shared-origin' if form == 1 else 'general'}{',exact' if exact else ''}>"
+                   f"<K={k},{('general', 'shared-origin', 'clustered')[form]}{',exact' if exact else ''}>"
             kernels.append(dict(kernel=name, launches=a["launches"], avg_ms=a["ms"] / a["launches"],
                                 total_ms=a["ms"], pairs_per_launch=pairs / a["launches"],
                                 tflops=pairs * FLOP_PER_TEST / (a["ms"] * 1e-3) / 1e12 if a["ms"] > 0 else 0.0))
@@ -224,7 +224,7 @@ def main():
             "config": {"workload": args.workload, "description": wl["desc"], "width": wl["width"],
                        "height": wl["height"], "views": len(wl["cams"]), "triangles": int(wl["mesh"].shape[0] // 3),
                        "passes": wl["passes"], "lights": wl["lights"], "sharding": shard_desc,
-                       "trace_mode": "filtered" if args.trace_mode == 0 else "exact",
+                       "trace_mode": ("filtered", "exact", "clustered")[args.trace_mode],
                        "rays_per_step": rays / steps,
                        "closest_hit_rays_per_step": tot[0] / steps, "shadow_rays_per_step": tot[1] / steps,
                        "pairs_per_step": (tot[2] + tot[3]) / steps,

@@ -82,10 +82,15 @@ typedef enum rt_status {
  *                       (ray, triangle) pair, followed by the reference's own
  *                       Moller-Trumbore arithmetic on the few pairs that pass.
  *   RT_TRACE_EXACT    : the reference's arithmetic on every pair (validation).
+ *   RT_TRACE_CLUSTERED: (the default) as FILTERED, but bounce rays first go through two
+ *                       cheaper conservative sweeps -- one dot product per pair against the
+ *                       triangle's plane, and one sphere test per cluster of 32 triangles --
+ *                       and only pairs these cannot reject reach the edge filter.
  */
 typedef enum rt_trace_mode {
-    RT_TRACE_FILTERED = 0,
-    RT_TRACE_EXACT    = 1
+    RT_TRACE_FILTERED  = 0,
+    RT_TRACE_EXACT     = 1,
+    RT_TRACE_CLUSTERED = 2
 } rt_trace_mode;
 
 typedef struct rt_ctx rt_ctx; /* opaque */
@@ -177,7 +182,8 @@ int rt_get_counters(rt_ctx *ctx, uint64_t counters[8]);
 /* One record per traversal-kernel launch made by rt_intersect / rt_color since
  * the last rt_kernel_log / rt_create (at most the 1024 most recent launches).
  *   stage : 1 = closest-hit traversal (rt_intersect), 2 = shadow traversal + shading (rt_color)
- *   form  : 0 = filter for arbitrary rays, 1 = filter for rays sharing an origin
+ *   form  : 0 = filter for arbitrary rays, 1 = filter for rays sharing an origin,
+ *           2 = clustered traversal of arbitrary rays
  *   rays_per_lane : 1, 2 or 4
  *   rays  : rays the launch traversed
  *   pairs : (ray, triangle) pairs = rays x triangles (x lights for stage 2; an

@@ -39,6 +39,7 @@ assert KERNEL_RECORD_DTYPE.itemsize == 40
 RT_MAX_LIGHTS = 10
 RT_TRACE_FILTERED = 0
 RT_TRACE_EXACT = 1
+RT_TRACE_CLUSTERED = 2
 
 # every symbol include/rt.h declares: name -> (restype, argtypes)
 _P = C.c_void_p

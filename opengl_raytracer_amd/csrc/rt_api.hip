@@ -15,6 +15,7 @@
 
 #include "../../include/rt.h"
 #include "rt_kernels.h"
+#include "rt_cluster.h"
 
 using namespace rtk;
 
@@ -50,6 +51,16 @@ struct rt_ctx {
     rtf::ConeRec *cone_camera = nullptr;
     rtf::ConeRec *cone_lights = nullptr; // RT_MAX_LIGHTS x rec_stride
     size_t rec_stride = 0;
+    // clustered traversal of arbitrary rays: plane bands per triangle, spheres / member records per cluster
+    float4 *ngroup_d = nullptr;
+    float4 *nband_d = nullptr;
+    float2 *nslab_d = nullptr;
+    int *nmember_d = nullptr;
+    int num_ngroups = 0;
+    float4 *sphere_d = nullptr;
+    rtf::TriRec *crec_d = nullptr;
+    int *member_d = nullptr;
+    int num_clusters = 0;
     bool camera_recs_dirty = true;
     bool light_recs_dirty = true;
 
@@ -83,7 +94,7 @@ struct rt_ctx {
     hipStream_t stream_own = nullptr;
     hipStream_t stream = nullptr;
 
-    int trace_mode = RT_TRACE_FILTERED;
+    int trace_mode = RT_TRACE_CLUSTERED;
 
     float acc_ms[3] = {0, 0, 0};
     std::vector<EventPair> ev_pool;
@@ -280,6 +291,13 @@ extern "C" void rt_destroy(rt_ctx *c)
     (void)hipFree(c->rec_lights);
     (void)hipFree(c->cone_camera);
     (void)hipFree(c->cone_lights);
+    (void)hipFree(c->ngroup_d);
+    (void)hipFree(c->nband_d);
+    (void)hipFree(c->nslab_d);
+    (void)hipFree(c->nmember_d);
+    (void)hipFree(c->sphere_d);
+    (void)hipFree(c->crec_d);
+    (void)hipFree(c->member_d);
     (void)hipFree(c->tex);
     (void)hipFree(c->list);
     (void)hipFree(c->alist[0]);
@@ -307,6 +325,15 @@ extern "C" int rt_set_mesh(rt_ctx *c, const rt_vertex *vertices, int num_vertice
     (void)hipFree(c->rec_lights); c->rec_lights = nullptr;
     (void)hipFree(c->cone_camera); c->cone_camera = nullptr;
     (void)hipFree(c->cone_lights); c->cone_lights = nullptr;
+    (void)hipFree(c->ngroup_d); c->ngroup_d = nullptr;
+    (void)hipFree(c->nband_d); c->nband_d = nullptr;
+    (void)hipFree(c->nslab_d); c->nslab_d = nullptr;
+    (void)hipFree(c->nmember_d); c->nmember_d = nullptr;
+    c->num_ngroups = 0;
+    (void)hipFree(c->sphere_d); c->sphere_d = nullptr;
+    (void)hipFree(c->crec_d); c->crec_d = nullptr;
+    (void)hipFree(c->member_d); c->member_d = nullptr;
+    c->num_clusters = 0;
     c->num_vertices = num_vertices;
     c->num_tris = num_vertices / 3;
     // record arrays are padded to whole tiles so that a tile copy never leaves the allocation
@@ -362,6 +389,38 @@ extern "C" int rt_set_mesh(rt_ctx *c, const rt_vertex *vertices, int num_vertice
     }
     for (int a = 0; a < 3; a++) c->center[a] = (float)ctr[a];
     c->radius = (float)(std::sqrt(r2) * 1.0001 + 1e-30);
+    {
+        // plane bands and clusters for the clustered traversal (needs the bounding sphere)
+        rtc::ClusterSet cs;
+        rtc::build(vertices, c->num_tris, c->center, c->radius, cs);
+        c->num_clusters = cs.num_clusters;
+        c->num_ngroups = cs.num_ngroups;
+        const size_t ng = (size_t)cs.num_ngroups, nc = (size_t)cs.num_clusters;
+        HIPCHK(c, hipMalloc(&c->ngroup_d, (ng + 1) * sizeof(float4)));
+        HIPCHK(c, hipMalloc(&c->nband_d, (ng * rtc::NGROUP + 1) * sizeof(float4)));
+        HIPCHK(c, hipMalloc(&c->nslab_d, (ng * rtc::NGROUP + 1) * sizeof(float2)));
+        HIPCHK(c, hipMalloc(&c->nmember_d, (ng * rtc::NGROUP + 1) * sizeof(int)));
+        HIPCHK(c, hipMalloc(&c->sphere_d, (nc + 1) * sizeof(float4)));
+        HIPCHK(c, hipMalloc(&c->crec_d, (nc * rtc::CLUSTER + 1) * sizeof(rtf::TriRec)));
+        HIPCHK(c, hipMalloc(&c->member_d, (nc * rtc::CLUSTER + 1) * sizeof(int)));
+        if (ng) {
+            HIPCHK(c, hipMemcpyAsync(c->ngroup_d, cs.ngroups.data(), ng * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->nband_d, cs.nbands.data(), ng * rtc::NGROUP * sizeof(float4),
+                                     hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->nslab_d, cs.nslabs.data(), ng * rtc::NGROUP * sizeof(float2),
+                                     hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->nmember_d, cs.nmembers.data(), ng * rtc::NGROUP * sizeof(int),
+                                     hipMemcpyHostToDevice, c->stream));
+        }
+        if (nc) {
+            HIPCHK(c, hipMemcpyAsync(c->sphere_d, cs.spheres.data(), nc * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->crec_d, cs.recs.data(), nc * rtc::CLUSTER * sizeof(rtf::TriRec),
+                                     hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->member_d, cs.members.data(), nc * rtc::CLUSTER * sizeof(int),
+                                     hipMemcpyHostToDevice, c->stream));
+        }
+        HIPCHK(c, hipStreamSynchronize(c->stream)); // the host vectors go out of scope
+    }
     c->have_mesh = true;
     c->camera_recs_dirty = true;
     c->light_recs_dirty = true;
@@ -447,7 +506,7 @@ extern "C" int rt_get_row_map(rt_ctx *c, int32_t *rows)
 extern "C" int rt_set_trace_mode(rt_ctx *c, int mode)
 {
     if (!c) return RT_ERR_ARG;
-    if (mode != RT_TRACE_FILTERED && mode != RT_TRACE_EXACT)
+    if (mode != RT_TRACE_FILTERED && mode != RT_TRACE_EXACT && mode != RT_TRACE_CLUSTERED)
         return fail(c, RT_ERR_ARG, "rt_set_trace_mode: unknown mode %d", mode);
     c->trace_mode = mode;
     return RT_OK;
@@ -603,6 +662,36 @@ static int launch_traverse(rt_ctx *c, TraverseParams p, int n_upper, int form, b
     return klog_end(c, ks);
 }
 
+// The clustered closest-hit traversal of arbitrary rays (form 2 in the kernel log).
+static int launch_traverse_clustered(rt_ctx *c, TraverseParams p, int n_upper)
+{
+    const int k = pick_rays_per_lane(n_upper);
+    const int ray_blocks = cdiv(n_upper, BLOCK * k);
+    const int tiles = cdiv(p.tri_end - p.tri_begin, TILE);
+    if (ray_blocks <= 0 || tiles <= 0) return RT_OK;
+    p.tiles_per_y = pick_tiles_per_y(ray_blocks, tiles);
+    p.tiles_per_y = (p.tiles_per_y + CONE_TILE / TILE - 1) / (CONE_TILE / TILE) * (CONE_TILE / TILE);
+    const dim3 grid(ray_blocks, cdiv(tiles, p.tiles_per_y));
+    p.ngroups = c->ngroup_d;
+    p.nbands = c->nband_d;
+    p.nslabs = c->nslab_d;
+    p.nmembers = c->nmember_d;
+    p.num_ngroups = c->num_ngroups;
+    p.spheres = c->sphere_d;
+    p.crecs = c->crec_d;
+    p.members = c->member_d;
+    p.num_clusters = c->num_clusters;
+    size_t ks;
+    if (int r = klog_begin(c, 1, 2, k, false, (unsigned long long)n_upper,
+                           (unsigned long long)n_upper * (unsigned long long)(p.tri_end - p.tri_begin), &ks))
+        return r;
+    if (k == 4) hipLaunchKernelGGL((traverse_cluster_kernel<4>), grid, dim3(BLOCK), 0, c->stream, p);
+    else if (k == 2) hipLaunchKernelGGL((traverse_cluster_kernel<2>), grid, dim3(BLOCK), 0, c->stream, p);
+    else hipLaunchKernelGGL((traverse_cluster_kernel<1>), grid, dim3(BLOCK), 0, c->stream, p);
+    HIPCHK(c, hipGetLastError());
+    return klog_end(c, ks);
+}
+
 static int refresh_camera_recs(rt_ctx *c)
 {
     if (c->camera_recs_dirty && c->num_tris) {
@@ -690,8 +779,9 @@ extern "C" int rt_intersect(rt_ctx *c)
             count = c->count_d;
         }
         if (n_upper > 0) {
+            const bool clustered = !shared && c->trace_mode == RT_TRACE_CLUSTERED;
             hipLaunchKernelGGL(intersect_setup_kernel, dim3(cdiv(n_upper, BLOCK)), dim3(BLOCK), 0, c->stream, c->rays,
-                               list, count, n_upper, c->job, c->scratch.best, shared ? 1 : 0,
+                               list, count, n_upper, c->job, c->scratch.best, shared ? 1 : (clustered ? 2 : 0),
                                shared_origin(c, c->cam.pos, 1.0f));
             HIPCHK(c, hipGetLastError());
             TraverseParams p{};
@@ -706,7 +796,11 @@ extern "C" int rt_intersect(rt_ctx *c)
             memcpy(p.origin, c->cam.pos, sizeof p.origin);
             p.tri_begin = 0;
             p.tri_end = c->num_tris;
-            if (int r = launch_traverse(c, p, n_upper, shared ? 1 : 0, false, 1)) return r;
+            if (clustered) {
+                if (int r = launch_traverse_clustered(c, p, n_upper)) return r;
+            } else if (int r = launch_traverse(c, p, n_upper, shared ? 1 : 0, false, 1)) {
+                return r;
+            }
             hipLaunchKernelGGL(intersect_finish_kernel, dim3(cdiv(n_upper, BLOCK)), dim3(BLOCK), 0, c->stream,
                                c->rays, list, count, n_upper, c->job, c->scratch.best, c->verts, c->num_tris, c->cam,
                                c->depth, c->counters_d);

@@ -1,0 +1,242 @@
+// rt_cluster.h -- host-side construction of the band records and triangle clusters that the
+// clustered traversal of arbitrary rays reads (theory: rt_filter.h, "Plane-band test and cluster
+// spheres").  Triangles are split by medians of their centroids (a k-d tree cut off at leaves of
+// CLUSTER triangles); each leaf gets a sphere that contains its triangles grown by their rho.
+// A second split, by the direction of the normal, gives the groups of the band sweep.
+// Host code only (rt_api.hip and the filter model test).
+#pragma once
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+#include "../../include/rt.h"
+#include "rt_filter.h"
+
+namespace rtc {
+
+constexpr int CLUSTER = 32;
+
+struct ClusterSet {
+    double S = 0.0;                      // the band records hold for rays with |o - X| <= S
+    double origin_limit = 0.0;           // ... which is every ray with |o - centre| <= origin_limit
+    std::vector<rtf::BandRec> bands;     // one per triangle, mesh order
+    std::vector<rtf::SlabRec> slabs;     // one per triangle, mesh order
+    std::vector<float> spheres;          // 4 per cluster: centre, R^2 (rounded up)
+    std::vector<int32_t> members;        // CLUSTER per cluster: triangle index or -1
+    std::vector<rtf::TriRec> recs;       // CLUSTER per cluster: general edge record of the member
+    int num_clusters = 0;
+    // triangles grouped by the direction of their normal: a ray's direction is in the band of a
+    // member only if it is in the group's band (axis, w): |axis . b| < w
+    std::vector<float> ngroups;          // 4 per group: axis, w (w = 2: every direction)
+    std::vector<rtf::BandRec> nbands;    // NGROUP per group: the member's own band record (theta = -1: padding)
+    std::vector<rtf::SlabRec> nslabs;    // NGROUP per group: and its slab record
+    std::vector<int32_t> nmembers;       // NGROUP per group: triangle index or -1
+    int num_ngroups = 0;
+};
+
+constexpr int NGROUP = 64;
+
+// Reorders idx[begin, end) so that consecutive runs of `leaf` elements are the leaves of a k-d
+// tree over the points pt(i) (3 doubles): split at the median rounded to a whole number of leaves,
+// across the axis of largest extent.
+template <class Point>
+inline void kd_order(std::vector<int32_t> &idx, size_t begin, size_t end, size_t leaf, const Point &pt)
+{
+    while (end - begin > leaf) {
+        double lo[3], hi[3];
+        for (size_t i = begin; i < end; i++) {
+            const double *q = pt(idx[i]);
+            for (int a = 0; a < 3; a++) {
+                if (i == begin || q[a] < lo[a]) lo[a] = q[a];
+                if (i == begin || q[a] > hi[a]) hi[a] = q[a];
+            }
+        }
+        int axis = 0;
+        for (int a = 1; a < 3; a++)
+            if (hi[a] - lo[a] > hi[axis] - lo[axis]) axis = a;
+        const size_t leaves = (end - begin + leaf - 1) / leaf;
+        const size_t mid = begin + (leaves / 2) * leaf;
+        std::nth_element(idx.begin() + begin, idx.begin() + mid, idx.begin() + end,
+                         [&](int32_t x, int32_t y) { return pt(x)[axis] < pt(y)[axis]; });
+        kd_order(idx, begin, mid, leaf, pt); // recurse left, loop right
+        begin = mid;
+    }
+}
+
+inline void build_normal_groups(ClusterSet &cs);
+
+inline void build(const rt_vertex *v, int num_tris, const float center[3], float radius, ClusterSet &out)
+{
+    out.S = 3.0 * (double)radius * 1.001;          // origin within 2R of the centre, vertex within R
+    out.origin_limit = 2.0 * (double)radius;
+    out.bands.assign((size_t)num_tris, rtf::BandRec{{0.0f, 0.0f, 0.0f, -1.0f}});
+    out.slabs.assign((size_t)num_tris, rtf::SlabRec{{0.0f, INFINITY}});
+    const double abs_extent = std::sqrt((double)center[0] * center[0] + (double)center[1] * center[1] +
+                                        (double)center[2] * center[2]) + 3.0 * (double)radius;
+    out.spheres.clear();
+    out.members.clear();
+    out.recs.clear();
+    out.num_clusters = 0;
+
+    std::vector<double> rho((size_t)num_tris, -1.0);
+    std::vector<int32_t> regular;
+    double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    std::vector<double> cen((size_t)num_tris * 3, 0.0);
+    const bool scene_ok = radius > 1e-6f && radius < 1e6f;
+    for (int t = 0; t < num_tris; t++) {
+        const float *X = v[3 * t].pos, *Y = v[3 * t + 1].pos, *Z = v[3 * t + 2].pos;
+        double r = rtf::make_band_rec(X, Y, Z, out.S, abs_extent, &out.bands[t], &out.slabs[t]);
+        if (r >= 0.0) {
+            // too large to sit in a cluster (a room's walls): keep it in the band for every ray
+            double c[3], far = 0.0;
+            for (int a = 0; a < 3; a++) c[a] = ((double)X[a] + Y[a] + Z[a]) / 3.0;
+            const float *P[3] = {X, Y, Z};
+            for (int k = 0; k < 3; k++) {
+                double d2 = 0.0;
+                for (int a = 0; a < 3; a++) d2 += (P[k][a] - c[a]) * (P[k][a] - c[a]);
+                far = std::max(far, std::sqrt(d2));
+            }
+            if (!scene_ok || !(far + r <= 0.25 * (double)radius)) {
+                out.bands[t].v[3] = INFINITY;
+                out.slabs[t].v[1] = INFINITY;
+                r = -1.0;
+            } else {
+                for (int a = 0; a < 3; a++) {
+                    cen[(size_t)t * 3 + a] = c[a];
+                    if (regular.empty() || c[a] < lo[a]) lo[a] = c[a];
+                    if (regular.empty() || c[a] > hi[a]) hi[a] = c[a];
+                }
+                regular.push_back(t);
+            }
+        }
+        rho[t] = r;
+    }
+
+    kd_order(regular, 0, regular.size(), CLUSTER, [&](int32_t t) { return &cen[(size_t)t * 3]; });
+    const std::vector<int32_t> &keyed = regular;
+    out.num_clusters = (int)((keyed.size() + CLUSTER - 1) / CLUSTER);
+    out.spheres.assign((size_t)out.num_clusters * 4, 0.0f);
+    out.members.assign((size_t)out.num_clusters * CLUSTER, -1);
+    out.recs.resize((size_t)out.num_clusters * CLUSTER);
+    for (auto &r : out.recs) rtf::nan_rec(&r);
+    for (int c = 0; c < out.num_clusters; c++) {
+        const size_t b = (size_t)c * CLUSTER, e = std::min(keyed.size(), b + CLUSTER);
+        double blo[3], bhi[3];
+        for (size_t i = b; i < e; i++) {
+            const int t = keyed[i];
+            for (int k = 0; k < 3; k++)
+                for (int a = 0; a < 3; a++) {
+                    const double x = v[3 * t + k].pos[a];
+                    if ((i == b && k == 0) || x < blo[a]) blo[a] = x;
+                    if ((i == b && k == 0) || x > bhi[a]) bhi[a] = x;
+                }
+        }
+        float cf[3];
+        for (int a = 0; a < 3; a++) cf[a] = (float)((blo[a] + bhi[a]) * 0.5);
+        double R = 0.0;
+        for (size_t i = b; i < e; i++) {
+            const int t = keyed[i];
+            out.members[b + (i - b)] = t;
+            rtf::make_general_rec(v[3 * t].pos, v[3 * t + 1].pos, v[3 * t + 2].pos, &out.recs[b + (i - b)]);
+            for (int k = 0; k < 3; k++) {
+                double d2 = 0.0;
+                for (int a = 0; a < 3; a++) {
+                    const double d = (double)v[3 * t + k].pos[a] - (double)cf[a];
+                    d2 += d * d;
+                }
+                R = std::max(R, std::sqrt(d2) + rho[t]);
+            }
+        }
+        const double cl = std::sqrt((double)cf[0] * cf[0] + (double)cf[1] * cf[1] + (double)cf[2] * cf[2]);
+        R = R * (1.0 + 1e-5) + 1e-6 * (cl + R); // float arithmetic on the centre in the kernel
+        float r2 = (float)(R * R);
+        if ((double)r2 < R * R) r2 = std::nextafterf(r2, INFINITY);
+        out.spheres[(size_t)c * 4 + 0] = cf[0];
+        out.spheres[(size_t)c * 4 + 1] = cf[1];
+        out.spheres[(size_t)c * 4 + 2] = cf[2];
+        out.spheres[(size_t)c * 4 + 3] = r2;
+    }
+    build_normal_groups(out);
+}
+
+// Groups the triangles that have a band (theta >= 0) by normal direction.  Normals are folded onto
+// one hemisphere (n and -n give the same band), mapped to the unit square (octahedral map) and
+// sorted along a Morton curve; groups are runs of NGROUP.  Triangles whose band is everything
+// (theta = inf) form groups of their own with w = 2.
+inline void build_normal_groups(ClusterSet &cs)
+{
+    const int n = (int)cs.bands.size();
+    std::vector<int32_t> keyed, always;
+    std::vector<double> folded((size_t)n * 3, 0.0);
+    for (int t = 0; t < n; t++) {
+        const float *b = cs.bands[t].v;
+        if (!(b[3] >= 0.0f)) continue;                 // never accepted
+        if (!(b[3] < INFINITY)) { always.push_back(t); continue; }
+        double x = b[0], y = b[1], z = b[2];
+        if (z < 0.0 || (z == 0.0 && (y < 0.0 || (y == 0.0 && x < 0.0)))) { x = -x; y = -y; z = -z; }
+        folded[(size_t)t * 3] = x; folded[(size_t)t * 3 + 1] = y; folded[(size_t)t * 3 + 2] = z;
+        keyed.push_back(t);
+    }
+    kd_order(keyed, 0, keyed.size(), NGROUP, [&](int32_t t) { return &folded[(size_t)t * 3]; });
+    const int g_reg = (int)((keyed.size() + NGROUP - 1) / NGROUP), g_alw = (int)((always.size() + NGROUP - 1) / NGROUP);
+    cs.num_ngroups = g_reg + g_alw;
+    cs.ngroups.assign((size_t)cs.num_ngroups * 4, 0.0f);
+    cs.nbands.assign((size_t)cs.num_ngroups * NGROUP, rtf::BandRec{{0.0f, 0.0f, 0.0f, -1.0f}});
+    cs.nslabs.assign((size_t)cs.num_ngroups * NGROUP, rtf::SlabRec{{0.0f, INFINITY}});
+    cs.nmembers.assign((size_t)cs.num_ngroups * NGROUP, -1);
+    for (int g = 0; g < g_reg; g++) {
+        const size_t b = (size_t)g * NGROUP, e = std::min(keyed.size(), b + NGROUP);
+        const float *first = cs.bands[keyed[b]].v;
+        double ax[3] = {0, 0, 0};
+        for (size_t i = b; i < e; i++) {
+            const float *m = cs.bands[keyed[i]].v;
+            const double sgn = ((double)m[0] * first[0] + (double)m[1] * first[1] + (double)m[2] * first[2]) < 0.0 ? -1.0 : 1.0;
+            for (int a = 0; a < 3; a++) ax[a] += sgn * m[a];
+        }
+        const double al = std::sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+        float axf[3] = {0.0f, 0.0f, 0.0f};
+        double w = 2.0;
+        if (al > 1e-6) {
+            for (int a = 0; a < 3; a++) axf[a] = (float)(ax[a] / al);
+            const double an = std::sqrt((double)axf[0] * axf[0] + (double)axf[1] * axf[1] + (double)axf[2] * axf[2]);
+            double alpha = 0.0, theta = 0.0;
+            for (size_t i = b; i < e; i++) {
+                const float *m = cs.bands[keyed[i]].v;
+                const double ml = std::sqrt((double)m[0] * m[0] + (double)m[1] * m[1] + (double)m[2] * m[2]);
+                double c = std::fabs((double)m[0] * axf[0] + (double)m[1] * axf[1] + (double)m[2] * axf[2]) / (ml * an);
+                if (c > 1.0) c = 1.0;
+                alpha = std::max(alpha, std::acos(c));
+                // the member's test is |m . b| < theta with |m| = ml: in angle, asin(theta / ml)
+                double sn = (double)m[3] / ml;
+                theta = std::max(theta, sn < 1.0 ? std::asin(sn) : 1.6);
+            }
+            const double half = alpha + theta + 4e-6; // |b| = 1 up to 4 eps, float dot product
+            if (half < 1.5) w = std::sin(half) * an * (1.0 + 1e-6) + 1e-6;
+        }
+        float wf = (float)w;
+        if ((double)wf < w) wf = std::nextafterf(wf, 4.0f);
+        cs.ngroups[(size_t)g * 4 + 0] = axf[0];
+        cs.ngroups[(size_t)g * 4 + 1] = axf[1];
+        cs.ngroups[(size_t)g * 4 + 2] = axf[2];
+        cs.ngroups[(size_t)g * 4 + 3] = wf;
+        for (size_t i = b; i < e; i++) {
+            cs.nbands[b + (i - b)] = cs.bands[keyed[i]];
+            cs.nslabs[b + (i - b)] = cs.slabs[keyed[i]];
+            cs.nmembers[b + (i - b)] = keyed[i];
+        }
+    }
+    for (int g = 0; g < g_alw; g++) {
+        const size_t b = (size_t)g * NGROUP, e = std::min(always.size(), b + NGROUP);
+        const size_t o = (size_t)(g_reg + g) * NGROUP;
+        cs.ngroups[(size_t)(g_reg + g) * 4 + 3] = 2.0f;
+        for (size_t i = b; i < e; i++) {
+            cs.nbands[o + (i - b)] = cs.bands[always[i]];
+            cs.nslabs[o + (i - b)] = cs.slabs[always[i]];
+            cs.nmembers[o + (i - b)] = always[i];
+        }
+    }
+}
+
+} // namespace rtc

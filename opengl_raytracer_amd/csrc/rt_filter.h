@@ -366,4 +366,112 @@ RT_HD double scene_extent(const float O[3], const float C[3], float R)
     return oc + (double)R + 0.125 * (o + c + (double)R);
 }
 
+// ---------------------------------------------------------------------------
+// Plane-band test and cluster spheres for arbitrary rays.
+//
+// Which pairs can the reference's arithmetic accept?  Write e1, e2 for the float edges it forms,
+// s = o - X, a = e1.(d x e2), Nu = s.(d x e2), Nv = d.(s x e1), and a^, Nu^, Nv^ for what it
+// computes.  First-order rounding analysis of its operation sequence gives
+//     |a^ - a| <= 7 eps |e1||e2||d|,  |Nu^ - Nu| <= 8 eps |s||d||e2|,  |Nv^ - Nv| <= 8 eps |s||d||e1|.
+// Let E = eps |d| max(16 S |e1|, 16 S |e2|, 14 |e1||e2|) with S >= |s| (twice those bounds).
+//   (A) |a^| >= K E.  Then u^ = Nu^/a^ (1 + 2 eps) differs from the true u = Nu/a by less than
+//       2/(K-1), likewise v; the reference accepts only 0 <= u^, 0 <= v^, u^ + v^ <= 1, so the point
+//       where the ray's LINE meets the triangle's plane lies within rho = 2/(K-1) (|e1| + |e2|) of
+//       the triangle: the line passes within rho of it.
+//   (B) |a^| < K E.  Then |a| < (K+1) E, i.e. the direction is nearly parallel to the plane:
+//       |d.n| / |d| < theta = (K+1) eps max(16 S / min(|e1|,|e2|), 14) / sin(angle(e1, e2)).
+//       In case (B) the reference accepts only if also |Nu^| <= |a^| and |Nv^| <= |a^| (u^, v^ <= 1),
+//       so Nu and Nv are below (K+1) E too; with m = s x d, Nu = m.e2, Nv = -m.e1, and
+//           s.n = (-(s.d) a + Nv (d.e2) + Nu (d.e1)) / |d|^2,    n = e1 x e2,
+//       the ray's origin then lies within  H = theta (S + |e1| + |e2|)  of the triangle's plane.
+// So a pair outside the slab (B) -- direction out of the band, or origin farther than H from the
+// plane -- whose line misses a sphere containing the triangle grown by rho is one the reference
+// rejects.  K = 17: rho = (|e1| + |e2|)/8.
+//
+// BandRec = (unit normal, theta').  theta' = theta + 2^-20 covers the float dot product with a
+// float-normalised direction.  theta' = +inf: every direction is in the band (slivers, edges
+// outside [1e-12, 1e12], triangles too large to cluster); theta' = -1: no direction is (triangles
+// the reference can never accept, padding).
+// ---------------------------------------------------------------------------
+struct BandRec {
+    float v[4];
+};
+// SlabRec = (kappa, H'): the origin test is |n.o - kappa| < H', kappa = n.X in float, H' = H plus
+// the rounding of n.o and kappa (<= 8 eps (|o| + |X|), bounded with abs_extent >= |o|, |X|).
+struct SlabRec {
+    float v[2];
+};
+
+constexpr double BAND_K = 17.0;
+
+// Fills the band record for rays with |o - X| <= S and returns rho (< 0 when the triangle takes
+// no part in clusters: it is never accepted, or always in the band).
+RT_HD double make_band_rec(const float X[3], const float Y[3], const float Z[3], double S, double abs_extent,
+                           BandRec *out, SlabRec *slab)
+{
+    float emax;
+    out->v[0] = out->v[1] = out->v[2] = 0.0f;
+    slab->v[0] = 0.0f;
+    slab->v[1] = INFINITY;
+    if (degenerate(X, Y, Z, &emax)) {
+        out->v[3] = -1.0f;
+        return -1.0;
+    }
+    out->v[3] = INFINITY;
+    const float e1f[3] = {Y[0] - X[0], Y[1] - X[1], Y[2] - X[2]};
+    const float e2f[3] = {Z[0] - X[0], Z[1] - X[1], Z[2] - X[2]};
+    const double e1[3] = {e1f[0], e1f[1], e1f[2]}, e2[3] = {e2f[0], e2f[1], e2f[2]};
+    double n[3];
+    cross3d(e1, e2, n);
+    const double l1 = sqrt(dot3d(e1, e1)), l2 = sqrt(dot3d(e2, e2)), nl = sqrt(dot3d(n, n));
+    const double emin = l1 < l2 ? l1 : l2, elong = l1 < l2 ? l2 : l1;
+    if (!(emin > 1e-12) || !(elong < 1e12) || !(nl > 0.0) || !(S > 0.0) || !(S < 1e12)) return -1.0;
+    const double sinphi = nl / (l1 * l2);
+    double w = 16.0 * S / emin;
+    if (w < 14.0) w = 14.0;
+    const double theta = (BAND_K + 1.0) * 5.9604644775390625e-08 * w / sinphi + 9.5367431640625e-07; // eps = 2^-24; 2^-20
+    if (!(theta < 0.5)) return -1.0;
+    out->v[0] = (float)(n[0] / nl);
+    out->v[1] = (float)(n[1] / nl);
+    out->v[2] = (float)(n[2] / nl);
+    float t = (float)theta;
+    if ((double)t < theta) t = nextafterf(t, 2.0f);
+    out->v[3] = t;
+    // kappa as the kernel would see it: float normal, double dot, rounded; the difference to the
+    // kernel's float dot product of n with o is inside the slack below
+    const double kappa = (double)out->v[0] * X[0] + (double)out->v[1] * X[1] + (double)out->v[2] * X[2];
+    const double H = theta * (S + l1 + l2) * 1.001 + 16.0 * 5.9604644775390625e-08 * abs_extent;
+    slab->v[0] = (float)kappa;
+    float h = (float)H;
+    if ((double)h < H) h = nextafterf(h, INFINITY);
+    slab->v[1] = h;
+    return 2.0 / (BAND_K - 1.0) * 1.02 * (l1 + l2);
+}
+
+// Origin within the slab?  rec = band record, slab = its SlabRec.
+RT_HD bool slab_test(const float *rec, const float *slab, float ox, float oy, float oz)
+{
+    const float h = fmaf(rec[2], oz, fmaf(rec[1], oy, rec[0] * ox)) - slab[0];
+    return fabsf(h) < slab[1];
+}
+
+// In the band?  (bx,by,bz) is the ray's direction normalised in float.
+RT_HD bool band_test(const float *rec, float bx, float by, float bz)
+{
+    const float t = fmaf(rec[2], bz, fmaf(rec[1], by, rec[0] * bx));
+    return fabsf(t) < rec[3];
+}
+
+// Does the line through (ox,oy,oz) along the float-normalised direction (bx,by,bz) pass within
+// the cluster's sphere?  rec = (centre, R^2 rounded up).  The 2^-20 |L|^2 slack covers the
+// cancellation in |L|^2 - (L.b)^2 and |b| != 1.
+RT_HD bool cluster_test(const float *rec, float ox, float oy, float oz, float bx, float by, float bz)
+{
+    const float lx = rec[0] - ox, ly = rec[1] - oy, lz = rec[2] - oz;
+    const float ll = fmaf(lz, lz, fmaf(ly, ly, lx * lx));
+    const float b = fmaf(lz, bz, fmaf(ly, by, lx * bx));
+    const float q = fmaf(-b, b, ll);
+    return fmaf(ll, -9.5367431640625e-07f, q) <= rec[3];
+}
+
 } // namespace rtf

@@ -274,6 +274,19 @@ __device__ __forceinline__ void prepare_shared(const Job &job, int slot, v3 o, v
     job.g[slot] = (reach <= reach_max) ? g : -g;
 }
 
+// fills job.b* and job.g for an arbitrary ray (clustered traversal): unit direction, and the
+// general filter's dir_scale, negated when the origin lies outside the range the band records
+// were built for (|o - centre| <= 2 radius)
+__device__ __forceinline__ void prepare_general(const Job &job, int slot, v3 o, v3 d, const float *center, float radius)
+{
+    const v3 oc = rtx::V(o.x - center[0], o.y - center[1], o.z - center[2]);
+    const float dist = sqrtf(rtx::dot(oc, oc));
+    const float g = rtf::dir_scale(dist + 3.0f * radius, d.x, d.y, d.z);
+    const float inv = 1.0f / sqrtf(rtx::dot(d, d));
+    job.bx[slot] = d.x * inv; job.by[slot] = d.y * inv; job.bz[slot] = d.z * inv;
+    job.g[slot] = (dist <= 2.0f * radius) ? g : -g;
+}
+
 struct SharedOrigin { // the shared origin of a launch and the validity range of its cones
     float origin[3];
     float center[3];
@@ -319,7 +332,8 @@ __global__ __launch_bounds__(BLOCK) void intersect_setup_kernel(RaySoA r, const 
     job.ox[slot] = o.x; job.oy[slot] = o.y; job.oz[slot] = o.z;
     job.dx[slot] = d.x; job.dy[slot] = d.y; job.dz[slot] = d.z;
     best[slot] = BEST_NONE;
-    if (shared) prepare_shared(job, slot, o, d, so.origin, so.center, so.radius, so.reach_max, so.sign);
+    if (shared == 1) prepare_shared(job, slot, o, d, so.origin, so.center, so.radius, so.reach_max, so.sign);
+    if (shared == 2) prepare_general(job, slot, o, d, so.center, so.radius);
 }
 
 // ---------------------------------------------------------------------------
@@ -362,6 +376,16 @@ struct TraverseParams {
     unsigned long long *best;
     int *occ;
     unsigned long long *counters;
+    // clustered traversal of arbitrary rays (traverse_cluster_kernel) only
+    const float4 *ngroups;      // one (axis, w) per group of triangles with similar normals
+    const float4 *nbands;       // the members' own (unit normal, theta), NGROUP per group; theta = -1: padding
+    const float2 *nslabs;       // and their (kappa, H): the origin must lie within H of the plane
+    const int *nmembers;        // triangle index of each of them, or -1
+    int num_ngroups;
+    const float4 *spheres;      // one (centre, R^2) per cluster of triangles close in space
+    const rtf::TriRec *crecs;   // the members' general edge records, CLUSTER per cluster
+    const int *members;         // triangle index of each of them, or -1
+    int num_clusters;
 };
 
 // cooperative copy of one tile of filter records into LDS; records past the end
@@ -399,6 +423,12 @@ constexpr int CONE_TILE = 1024; // triangles per LDS tile of cone records (16 Ki
 // candidate queue entries per wavefront: one triangle can add 64 K entries, and draining
 // starts once fewer than that are free
 __host__ __device__ constexpr int qcap(int K) { return 64 * K + 256; }
+
+// value of `v` in lane `src` (wave-uniform lane index): one v_readlane_b32
+__device__ __forceinline__ float readlane_f(float v, int src)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
 
 // number of set bits of `mask` below this lane
 __device__ __forceinline__ int lanes_below(unsigned long long mask)
@@ -685,6 +715,243 @@ __global__ __launch_bounds__(BLOCK) void traverse_kernel(TraverseParams p)
                 ((unsigned long long)__float_as_uint(tbest[k]) << 32) | (unsigned long long)(unsigned int)idbest[k];
             atomicMin(&p.best[slot[k]], key);
         }
+    }
+}
+
+
+// ---------------------------------------------------------------------------
+// Clustered closest-hit traversal of arbitrary rays (bounce passes).  Same result as
+// traverse_kernel<K, 0, false, *>, bit for bit, from two sweeps over GROUPS of triangles that
+// together cover every pair the reference's arithmetic could accept (rt_filter.h, "Plane-band
+// test and cluster spheres"):
+//   sweep A  triangles grouped by normal direction, 64 per group: is the ray's direction in the
+//            group's band?  For each ray that is, one lane per member tests the member's own
+//            band; pairs inside go to a queue and from there, one per lane, through the general
+//            edge filter and the reference arithmetic.
+//   sweep B  triangles grouped in space, 32 per cluster: does the ray's line pass the cluster's
+//            sphere?  For each ray that does (two per step), one lane per member runs the
+//            general edge filter on the member's record, then the reference arithmetic.
+// A wavefront tests its 64 K rays against a group with one ballot per K, loads the group's member
+// records once and then walks the set bits.  Results merge through the 64-bit atomicMin on
+// (t bits, index), so the visiting order does not matter.  The workgroup's rays are staged in
+// LDS so that any lane can fetch any of them.
+// grid = (ray blocks, sub-ranges): blockIdx.y takes a share of the groups of either kind.
+// ---------------------------------------------------------------------------
+constexpr int CLUSTER = 32;
+constexpr int NGROUP = 64;
+constexpr int GROUP_TILE = 512; // group records per LDS tile (8 KiB)
+
+template <int K>
+__global__ __launch_bounds__(BLOCK) void traverse_cluster_kernel(TraverseParams p)
+{
+    constexpr int NR = BLOCK * K;
+    __shared__ float4 tile[GROUP_TILE];
+    __shared__ float rox[NR], roy[NR], roz[NR], rdx[NR], rdy[NR], rdz[NR], rg[NR];
+    __shared__ int rslot[NR];
+    __shared__ unsigned int queue_all[(BLOCK / 64) * qcap(1)];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = p.count ? *p.count : p.n;
+    const int s0 = blockIdx.x * NR;
+    if (s0 >= n) return;
+    const int g_per_y = (p.num_ngroups + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int g_begin = blockIdx.y * g_per_y, g_end = min(g_begin + g_per_y, p.num_ngroups);
+    const int c_per_y = (p.num_clusters + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int c_begin = blockIdx.y * c_per_y, c_end = min(c_begin + c_per_y, p.num_clusters);
+
+    float ox[K], oy[K], oz[K], bx[K], by[K], bz[K];
+    bool valid[K], wild[K];
+    const float qn = __int_as_float(0x7fc00000);
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int r = (wave * K + k) * 64 + lane;
+        const int s = s0 + r;
+        valid[k] = s < n;
+        const int sl = valid[k] ? (p.alist ? p.alist[s] : s) : 0;
+        ox[k] = oy[k] = oz[k] = bx[k] = by[k] = bz[k] = qn;
+        float dx = qn, dy = qn, dz = qn, g = qn;
+        if (valid[k]) {
+            ox[k] = p.job.ox[sl]; oy[k] = p.job.oy[sl]; oz[k] = p.job.oz[sl];
+            dx = p.job.dx[sl]; dy = p.job.dy[sl]; dz = p.job.dz[sl];
+            bx[k] = p.job.bx[sl]; by[k] = p.job.by[sl]; bz[k] = p.job.bz[sl];
+            g = p.job.g[sl];
+        }
+        // outside the range the band records were built for: every band holds this ray
+        wild[k] = valid[k] && !(g > 0.0f);
+        rox[r] = ox[k]; roy[r] = oy[k]; roz[r] = oz[k];
+        rdx[r] = dx; rdy[r] = dy; rdz[r] = dz;
+        rg[r] = fabsf(g);
+        rslot[r] = sl;
+    }
+    unsigned long long wild_mask[K], valid_mask[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        wild_mask[k] = __builtin_amdgcn_ballot_w64(wild[k]);
+        valid_mask[k] = __builtin_amdgcn_ballot_w64(valid[k]);
+    }
+
+    unsigned int *queue = queue_all + wave * qcap(1);
+    int qcount = 0; // wave-uniform
+    unsigned long long n_cand = 0, n_slow = 0;
+
+    // the reference arithmetic on one pair whose edge filter passed
+    auto confirm = [&](int r, int tri) {
+        const v3 o = rtx::V(rox[r], roy[r], roz[r]), d = rtx::V(rdx[r], rdy[r], rdz[r]);
+        const v3 X = vpos(p.verts, 3 * tri), Y = vpos(p.verts, 3 * tri + 1), Z = vpos(p.verts, 3 * tri + 2);
+        float t;
+        if (rtx::ray_vs_triangle(o, d, X, Y, Z, t) && t > 0.0f) {
+            const unsigned long long key =
+                ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)(unsigned int)tri;
+            atomicMin(&p.best[rslot[r]], key);
+        }
+    };
+
+    // sweep A's queue: (triangle, ray) pairs inside a plane band, one per lane
+    auto drain_pairs = [&](bool all) {
+#ifdef RT_DBG_NO_DRAIN
+        qcount = 0;
+        return;
+#endif
+        while (qcount >= 64 || (all && qcount > 0)) {
+            const int take = qcount >= 64 ? 64 : qcount;
+            qcount -= take;
+            bool pass = false;
+            int tri = 0, r = 0;
+            if (lane < take) {
+                const unsigned int e = queue[qcount + lane];
+                r = (int)(e & 2047u);
+                tri = (int)(e >> 11);
+                const float gg = rg[r];
+                pass = rtf::filter_general(reinterpret_cast<const float *>(p.recs + tri), rox[r], roy[r], roz[r],
+                                           rdx[r] * gg, rdy[r] * gg, rdz[r] * gg) >= -1.0f;
+            }
+            n_cand += __popcll(__builtin_amdgcn_ballot_w64(pass));
+            if (pass) confirm(r, tri);
+        }
+    };
+
+    __syncthreads(); // the staged rays
+
+    // ---- sweep A: groups by normal direction
+#ifdef RT_DBG_NO_A
+    if (false)
+#endif
+    for (int tile_base = g_begin; tile_base < g_end; tile_base += GROUP_TILE) {
+        __syncthreads();
+        const int tile_n = min(GROUP_TILE, g_end - tile_base);
+#pragma unroll
+        for (int i = 0; i < GROUP_TILE / BLOCK; i++) {
+            const int e = i * BLOCK + tid;
+            if (e < tile_n) tile[e] = p.ngroups[tile_base + e];
+        }
+        __syncthreads();
+        for (int j = 0; j < tile_n; j++) {
+            const float4 c = tile[j];
+            unsigned long long m[K], any = 0;
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                const float t = fabsf(fmaf(c.z, bz[k], fmaf(c.y, by[k], c.x * bx[k])));
+                m[k] = (__builtin_amdgcn_ballot_w64(t < c.w) | wild_mask[k]) & valid_mask[k];
+                any |= m[k];
+            }
+            if (!any) continue;
+            n_slow++;
+            // one lane per member: its own band record
+            const int idx = (tile_base + j) * NGROUP + lane;
+            const float4 mb = p.nbands[idx];
+            const float2 ms = p.nslabs[idx];
+            const int tri = p.nmembers[idx];
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                unsigned long long mk = m[k];
+                while (mk) {
+                    const int src = __builtin_ctzll(mk);
+                    mk &= mk - 1;
+                    const float rbx = readlane_f(bx[k], src), rby = readlane_f(by[k], src), rbz = readlane_f(bz[k], src);
+                    const float rox_ = readlane_f(ox[k], src), roy_ = readlane_f(oy[k], src), roz_ = readlane_f(oz[k], src);
+                    const float t = fabsf(fmaf(mb.z, rbz, fmaf(mb.y, rby, mb.x * rbx)));
+                    const float hgt = fabsf(fmaf(mb.z, roz_, fmaf(mb.y, roy_, mb.x * rox_)) - ms.x);
+                    const bool w = (wild_mask[k] >> src) & 1ull;
+                    const bool in = (((t < mb.w) && (hgt < ms.y)) || (w && mb.w >= 0.0f)) && tri >= 0;
+                    const unsigned long long h = __builtin_amdgcn_ballot_w64(in);
+                    if (h) {
+                        if (in)
+                            queue[qcount + lanes_below(h)] =
+                                ((unsigned int)tri << 11) | (unsigned int)((wave * K + k) * 64 + src);
+                        qcount += __popcll(h);
+                        if (qcount >= qcap(1) - 64) drain_pairs(false);
+                    }
+                }
+            }
+        }
+    }
+    drain_pairs(true);
+
+    // ---- sweep B: clusters in space (a ray outside the records' range is in every band, so sweep A
+    //      has queued all its pairs)
+#ifdef RT_DBG_NO_B
+    if (false)
+#endif
+    for (int tile_base = c_begin; tile_base < c_end; tile_base += GROUP_TILE) {
+        __syncthreads();
+        const int tile_n = min(GROUP_TILE, c_end - tile_base);
+#pragma unroll
+        for (int i = 0; i < GROUP_TILE / BLOCK; i++) {
+            const int e = i * BLOCK + tid;
+            if (e < tile_n) tile[e] = p.spheres[tile_base + e];
+        }
+        __syncthreads();
+        for (int j = 0; j < tile_n; j++) {
+            const float4 c = tile[j];
+            unsigned long long m[K], any = 0;
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                const bool in = rtf::cluster_test(&c.x, ox[k], oy[k], oz[k], bx[k], by[k], bz[k]);
+                m[k] = __builtin_amdgcn_ballot_w64(in) & ~wild_mask[k];
+                any |= m[k];
+            }
+            if (!any) continue;
+            n_slow++;
+            // one lane per member (twice): its general edge record
+            const int idx = (tile_base + j) * CLUSTER + (lane & 31);
+            const float4 *rp = reinterpret_cast<const float4 *>(p.crecs + idx);
+            const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
+            const float rec[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
+            const int tri = p.members[idx];
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                unsigned long long mk = m[k];
+                while (mk) {
+                    // the lower half of the wavefront takes the lowest set bit, the upper half the next
+                    const int s0b = __builtin_ctzll(mk);
+                    mk &= mk - 1;
+                    int s1b = -1;
+                    if (mk) {
+                        s1b = __builtin_ctzll(mk);
+                        mk &= mk - 1;
+                    }
+                    const int src = (lane < 32) ? s0b : s1b;
+                    bool pass = false;
+                    int r = 0;
+                    if (src >= 0 && tri >= 0) {
+                        r = (wave * K + k) * 64 + src;
+                        const float gg = rg[r];
+                        pass = rtf::filter_general(rec, rox[r], roy[r], roz[r], rdx[r] * gg, rdy[r] * gg, rdz[r] * gg) >= -1.0f;
+                    }
+                    n_cand += __popcll(__builtin_amdgcn_ballot_w64(pass));
+                    if (pass) confirm(r, tri);
+                }
+            }
+        }
+    }
+
+    if (lane == 0) {
+        add_counter(p.counters, C_CH_CAND, n_cand);
+        add_counter(p.counters, C_CH_SLOW, n_slow);
+    }
+    if (tid == 0 && blockIdx.y == 0) {
+        const int mine = min(NR, n - s0);
+        add_counter(p.counters, C_CH_PAIRS, (unsigned long long)mine * (unsigned long long)p.num_tris);
     }
 }
 

@@ -37,7 +37,7 @@ def assert_same_pixels(tag, gpu, cpu):
 
 
 # -- committed golden vectors ---------------------------------------------------------
-@pytest.mark.parametrize("mode", [0, 1], ids=["filtered", "exact"])
+@pytest.mark.parametrize("mode", [0, 1, 2], ids=["filtered", "exact", "clustered"])
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
 def test_golden_vectors(rt, path, mode):
     case = load_case(path)
@@ -48,6 +48,7 @@ def test_golden_vectors(rt, path, mode):
 
 
 # -- seeded scenes against the oracle run side by side ------------------------------------
+@pytest.mark.parametrize("mode", [2, 0], ids=["clustered", "filtered"])
 @pytest.mark.parametrize("kind,w,h,passes,nl", [
     ("mixed", 128, 128, 3, 2),
     ("soup", 160, 96, 2, 1),
@@ -55,10 +56,11 @@ def test_golden_vectors(rt, path, mode):
     ("mixed", 37, 5, 2, 10),     # ragged: 185 rays, not a multiple of the 4-ray vector stores
     ("soup", 1, 1, 2, 1),        # a single ray
 ])
-def test_stage_by_stage_against_oracle(rt, oracle_mod, kind, w, h, passes, nl):
+def test_stage_by_stage_against_oracle(rt, oracle_mod, kind, w, h, passes, nl, mode):
     sc = small_scene(kind)
     g, c = make_pair(rt, oracle_mod, w, h)
     with g:
+        g.set_trace_mode(mode)
         setup(g, sc, nl)
         setup(c, sc, nl)
         g.raygen(); c.raygen()
@@ -122,7 +124,8 @@ def test_zero_lights_all_grey(rt, oracle_mod):
         assert (g.read_pixels().reshape(-1, 4) == [26, 26, 26, 255]).all()
 
 
-def test_hand_written_rays_nan_inf_and_dead(rt, oracle_mod):
+@pytest.mark.parametrize("mode", [2, 0], ids=["clustered", "filtered"])
+def test_hand_written_rays_nan_inf_and_dead(rt, oracle_mod, mode):
     """rt_write_rays with hostile records: dead rays, NaN/inf origins and directions, zero
     direction, rays starting on a triangle, rays along an edge."""
     sc = small_scene("mixed")
@@ -147,7 +150,20 @@ def test_hand_written_rays_nan_inf_and_dead(rt, oracle_mod):
     rays["origin"][9] = verts[0]                      # starts on a vertex
     rays["origin"][10] = (verts[0] + verts[1]) / 2    # starts on an edge
     rays["dir"][10] = (verts[1] - verts[0]) / np.linalg.norm(verts[1] - verts[0])  # along it
+    # rays lying in triangle planes, starting far outside the triangle (and outside the scene)
+    for i, t in enumerate(range(0, 60, 3)):
+        a, b, cc = verts[3 * t].astype(np.float64), verts[3 * t + 1].astype(np.float64), verts[3 * t + 2].astype(np.float64)
+        inplane = (b - a) * rs.uniform(-1, 1) + (cc - a) * rs.uniform(-1, 1)
+        inplane /= np.linalg.norm(inplane)
+        start = a + (b - a) * rs.uniform(-30, 30) + (cc - a) * rs.uniform(-30, 30)
+        rays["origin"][20 + i] = start
+        rays["dir"][20 + i] = inplane if i % 2 else (a + 0.3 * (b - a) + 0.3 * (cc - a) - start) / np.linalg.norm(a + 0.3 * (b - a) + 0.3 * (cc - a) - start)
+    rays["primitiveID"][20:40] = -1
+    rays["origin"][45] = (50.0, 20.0, -70.0)             # far outside the scene, aimed at it
+    rays["dir"][45] = -rays["origin"][45] / np.linalg.norm(rays["origin"][45])
+    rays["primitiveID"][45] = -1
     with g:
+        g.set_trace_mode(mode)
         setup(g, sc, 2); setup(c, sc, 2)
         g.write_rays(rays); c.write_rays(rays)
         back = g.read_rays()
@@ -160,7 +176,8 @@ def test_hand_written_rays_nan_inf_and_dead(rt, oracle_mod):
             assert_same_pixels(f"color {p}", g, c)
 
 
-def test_degenerate_triangles(rt, oracle_mod):
+@pytest.mark.parametrize("mode", [2, 0], ids=["clustered", "filtered"])
+def test_degenerate_triangles(rt, oracle_mod, mode):
     from opengl_raytracer_amd import scenes
     sc = small_scene("soup")
     mesh = sc["mesh"].copy()
@@ -173,13 +190,15 @@ def test_degenerate_triangles(rt, oracle_mod):
     sc["mesh"] = mesh
     g, c = make_pair(rt, oracle_mod, 96, 96)
     with g:
+        g.set_trace_mode(mode)
         setup(g, sc, 1); setup(c, sc, 1)
-        g.render(2); c.render(2)
+        g.render(3); c.render(3)
         assert_same("degenerate", g, c)
         assert_same_pixels("degenerate", g, c)
 
 
-def test_scene_far_from_world_origin(rt, oracle_mod):
+@pytest.mark.parametrize("mode", [2, 0], ids=["clustered", "filtered"])
+def test_scene_far_from_world_origin(rt, oracle_mod, mode):
     """Large coordinates stress the filter's error bound (absolute rounding grows)."""
     sc = small_scene("soup")
     off = f32([900.0, -400.0, 250.0])
@@ -193,8 +212,9 @@ def test_scene_far_from_world_origin(rt, oracle_mod):
     sc["lights"] = lights
     g, c = make_pair(rt, oracle_mod, 128, 96)
     with g:
+        g.set_trace_mode(mode)
         setup(g, sc, 1); setup(c, sc, 1)
-        g.render(2); c.render(2)
+        g.render(3); c.render(3)
         assert_same("far", g, c)
         assert_same_pixels("far", g, c)
 
@@ -227,8 +247,8 @@ def test_row_tiles_union_is_the_whole_frame(rt):
 # -- size-independent properties at the benchmark's full size ----------------------------------
 def test_full_size_filtered_equals_exact_and_is_idempotent(rt):
     """3840x2160 rays against a 64K-triangle soup is far beyond what the CPU oracle can do in
-    a test, so parity at full size is checked through properties: (1) the filtered traversal
-    and the all-pairs exact traversal give bit-identical rays and pixels, (2) rendering twice
+    a test, so parity at full size is checked through properties: (1) the clustered (default), the
+    filtered and the all-pairs exact traversal give bit-identical rays and pixels, (2) rendering twice
     gives identical bits, (3) counters are consistent."""
     from opengl_raytracer_amd import scenes
     w, h = 3840, 2160
@@ -254,12 +274,13 @@ def test_full_size_filtered_equals_exact_and_is_idempotent(rt):
         rays_f, pix_f = g.read_rays(), g.read_pixels()
         assert not rays_equal_bits(rays_f, rays_a.reshape(h, w)[rows].reshape(-1)).any()
         assert np.array_equal(pix_f, pix_a[rows])
-        g.set_trace_mode(rt.RT_TRACE_EXACT)
-        g.render(2)
-        rays_c, pix_c = g.read_rays(), g.read_pixels()
-        bad = rays_equal_bits(rays_f, rays_c)
-        assert not bad.any(), describe_mismatch(rays_f, rays_c, bad)
-        assert np.array_equal(pix_f, pix_c)
+        for other in (rt.RT_TRACE_FILTERED, rt.RT_TRACE_EXACT):
+            g.set_trace_mode(other)
+            g.render(2)
+            rays_c, pix_c = g.read_rays(), g.read_pixels()
+            bad = rays_equal_bits(rays_f, rays_c)
+            assert not bad.any(), f"mode {other}: " + describe_mismatch(rays_f, rays_c, bad)
+            assert np.array_equal(pix_f, pix_c)
         # pass 1 traces every pixel's ray against every triangle
         assert cnt["closest_rays"] >= w * h
         assert cnt["closest_pairs"] >= w * h * 65536
@@ -308,5 +329,5 @@ def test_stage_timers_and_counters(rt):
         log = g.kernel_log()
         assert [int(x) for x in log["stage"]] == [1, 2, 1, 2]
         assert (log["ms"] > 0).all() and (log["pairs"] > 0).all()
-        assert log["form"][0] == 1 and log["form"][2] == 0   # fresh rays share the camera origin
+        assert log["form"][0] == 1 and log["form"][2] == 2   # fresh rays share the camera origin; bounce rays: clustered
         assert g.kernel_log().shape[0] == 0
