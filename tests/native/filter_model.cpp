@@ -120,3 +120,93 @@ extern "C" void fm_check_cone(int n_tris, const float *verts, int n_rays, const 
     }
     stats[0] = pairs; stats[1] = p1; stats[2] = p2; stats[3] = acc; stats[4] = bad; stats[5] = always; stats[6] = wildn;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Clustered traversal of arbitrary rays, as traverse_cluster_kernel evaluates it: a pair reaches
+// the reference arithmetic iff
+//   (its triangle's normal group holds the ray's direction AND the triangle's own band and slab
+//    hold the ray, or the ray is outside the records' range)  AND the general edge filter passes,
+//   OR  (the ray is inside the range AND its line passes the sphere of the triangle's cluster)
+//        AND the general edge filter passes.
+// stats: [0] pairs [1] (ray, group) band passes x members [2] member band+slab passes
+//        [3] pairs inside a cluster sphere [4] pairs reaching the reference arithmetic
+//        [5] oracle accepts [6] violations [7] rays outside the records' range
+//        [8] triangles in no cluster [9] triangles that are never accepted
+// ---------------------------------------------------------------------------------------------
+#include "../../opengl_raytracer_amd/csrc/rt_cluster.h"
+
+extern "C" void fm_check_clustered(int n_tris, const float *verts, int n_rays, const float *org, const float *dir,
+                                   const float *center, float radius, long long *stats)
+{
+    std::vector<rt_vertex> v((size_t)n_tris * 3);
+    for (int i = 0; i < n_tris * 3; i++) {
+        v[i] = rt_vertex{};
+        v[i].pos[0] = verts[3 * i]; v[i].pos[1] = verts[3 * i + 1]; v[i].pos[2] = verts[3 * i + 2];
+    }
+    rtc::ClusterSet cs;
+    rtc::build(v.data(), n_tris, center, radius, cs);
+    std::vector<int> group_of(n_tris, -1), gpos(n_tris, -1), cluster_of(n_tris, -1), cpos(n_tris, -1);
+    for (int g = 0; g < cs.num_ngroups; g++)
+        for (int j = 0; j < rtc::NGROUP; j++) {
+            const int t = cs.nmembers[(size_t)g * rtc::NGROUP + j];
+            if (t >= 0) { group_of[t] = g; gpos[t] = g * rtc::NGROUP + j; }
+        }
+    for (int c = 0; c < cs.num_clusters; c++)
+        for (int j = 0; j < rtc::CLUSTER; j++) {
+            const int t = cs.members[(size_t)c * rtc::CLUSTER + j];
+            if (t >= 0) { cluster_of[t] = c; cpos[t] = c * rtc::CLUSTER + j; }
+        }
+    long long pairs = 0, gp = 0, mp = 0, sp = 0, reach_exact = 0, acc = 0, bad = 0, wildn = 0, noclu = 0, never = 0;
+    for (int k = 0; k < n_tris; k++) {
+        noclu += cluster_of[k] < 0;
+        never += group_of[k] < 0;
+    }
+#pragma omp parallel for reduction(+ : pairs, gp, mp, sp, reach_exact, acc, bad, wildn) schedule(static)
+    for (int i = 0; i < n_rays; i++) {
+        const float *o = org + 3 * i, *d = dir + 3 * i;
+        // prepare_general
+        const float ocx = o[0] - center[0], ocy = o[1] - center[1], ocz = o[2] - center[2];
+        const float dist = sqrtf(ocx * ocx + ocy * ocy + ocz * ocz);
+        const float g0 = rtf::dir_scale(dist + 3.0f * radius, d[0], d[1], d[2]);
+        const float inv = 1.0f / sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        const float bx = d[0] * inv, by = d[1] * inv, bz = d[2] * inv;
+        const float g = (dist <= 2.0f * radius) ? g0 : -g0;
+        const bool wild = !(g > 0.0f);
+        const float gg = fabsf(g);
+        wildn += wild;
+        for (int k = 0; k < n_tris; k++) {
+            const float *X = verts + 9 * k, *Y = X + 3, *Z = X + 6;
+            bool to_exact = false;
+            if (group_of[k] >= 0) {
+                const float *G = &cs.ngroups[(size_t)group_of[k] * 4];
+                const float tg = fabsf(fmaf(G[2], bz, fmaf(G[1], by, G[0] * bx)));
+                if (tg < G[3] || wild) {
+                    gp++;
+                    const float *mb = cs.nbands[gpos[k]].v, *ms = cs.nslabs[gpos[k]].v;
+                    const float t = fabsf(fmaf(mb[2], bz, fmaf(mb[1], by, mb[0] * bx)));
+                    const float hgt = fabsf(fmaf(mb[2], o[2], fmaf(mb[1], o[1], mb[0] * o[0])) - ms[0]);
+                    if (((t < mb[3]) && (hgt < ms[1])) || (wild && mb[3] >= 0.0f)) {
+                        mp++;
+                        rtf::TriRec rec;
+                        rtf::make_general_rec(X, Y, Z, &rec);
+                        to_exact = rtf::filter_general(rec.v, o[0], o[1], o[2], d[0] * gg, d[1] * gg, d[2] * gg) >= -1.0f;
+                    }
+                }
+            }
+            if (!to_exact && cluster_of[k] >= 0 && !wild) {
+                if (rtf::cluster_test(&cs.spheres[(size_t)cluster_of[k] * 4], o[0], o[1], o[2], bx, by, bz)) {
+                    sp++;
+                    to_exact = rtf::filter_general(cs.recs[cpos[k]].v, o[0], o[1], o[2], d[0] * gg, d[1] * gg, d[2] * gg) >= -1.0f;
+                }
+            }
+            float t;
+            const bool a = rto_ray_vs_triangle(o, d, X, Y, Z, &t) != 0 && t > 0.0f;
+            pairs++;
+            reach_exact += to_exact;
+            acc += a;
+            bad += (a && !to_exact);
+        }
+    }
+    stats[0] = pairs; stats[1] = gp; stats[2] = mp; stats[3] = sp; stats[4] = reach_exact; stats[5] = acc;
+    stats[6] = bad; stats[7] = wildn; stats[8] = noclu; stats[9] = never;
+}

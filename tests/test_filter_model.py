@@ -329,3 +329,142 @@ def test_cone_cascade_wild_rays_fall_back_to_the_edge_filter(fm):
     st = run_cone(fm, tris, L, org, ld, -1.0, np.full(ld.shape[0], 1e9, dtype=f32))
     assert st["bad"] == 0, st
     assert st["wild"] == ld.shape[0]
+
+
+# -- clustered traversal of arbitrary rays (normal groups + band/slab, spatial clusters) ---------
+CL_KEYS = ["pairs", "group", "member", "sphere", "to_exact", "accepts", "bad", "wild", "unclustered", "never"]
+
+
+def run_clustered(fm, tris, org, dirs, sphere=None):
+    c, r = bounding_sphere(tris) if sphere is None else sphere
+    stats = (C.c_longlong * 10)()
+    tris = np.ascontiguousarray(tris, dtype=f32)
+    org = np.ascontiguousarray(org, dtype=f32)
+    dirs = np.ascontiguousarray(dirs, dtype=f32)
+    fm.fm_check_clustered.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
+                                      C.c_void_p]
+    fm.fm_check_clustered(tris.shape[0], tris.ctypes.data, org.shape[0], org.ctypes.data, dirs.ctypes.data,
+                          c.ctypes.data, r, stats)
+    return dict(zip(CL_KEYS, list(stats)))
+
+
+def bounce_like_rays(rs, tris, n, extent, offset):
+    """Origins on triangles, directions random -- what a bounce pass traces."""
+    k = rs.randint(0, tris.shape[0], n)
+    w = rs.dirichlet([1, 1, 1], size=n)
+    p = (w[:, :, None] * tris[k].astype(np.float64)).sum(1)
+    d = rs.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return (p + d * 0.001).astype(f32), d.astype(f32)
+
+
+def in_plane_rays(rs, tris, n, spread):
+    """Rays lying in (or tilted out of, by 1e-9 .. 1e-2 rad) the plane of a triangle, starting up to
+    `spread` edge lengths away from it: where the reference's arithmetic accepts from rounding noise."""
+    k = rs.randint(0, tris.shape[0], n)
+    t = tris[k].astype(np.float64)
+    e1, e2 = t[:, 1] - t[:, 0], t[:, 2] - t[:, 0]
+    nrm = np.cross(e1, e2)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True) + 1e-300
+    a, b = rs.uniform(-spread, spread, (n, 1)), rs.uniform(-spread, spread, (n, 1))
+    start = t[:, 0] + a * e1 + b * e2
+    # aim at a point of the triangle (half of them) or anywhere in the plane
+    w = rs.dirichlet([1, 1, 1], size=n)
+    target = (w[:, :, None] * t).sum(1)
+    anywhere = t[:, 0] + rs.uniform(-spread, spread, (n, 1)) * e1 + rs.uniform(-spread, spread, (n, 1)) * e2
+    target[1::2] = anywhere[1::2]
+    d = target - start
+    d /= np.linalg.norm(d, axis=1, keepdims=True) + 1e-300
+    tilt = 10.0 ** rs.uniform(-9, -2, (n, 1)) * rs.choice([-1, 0, 1], size=(n, 1))
+    d = d + nrm * tilt
+    d /= np.linalg.norm(d, axis=1, keepdims=True) + 1e-300
+    lift = 10.0 ** rs.uniform(-9, -3, (n, 1)) * rs.choice([-1, 0, 1], size=(n, 1))
+    start = start + nrm * lift * np.linalg.norm(e1, axis=1, keepdims=True)
+    return start.astype(f32), d.astype(f32)
+
+
+@pytest.mark.parametrize("sc", SCENES, ids=[s["name"] for s in SCENES])
+def test_clustered_path_is_conservative(fm, sc):
+    rs = np.random.RandomState(71)
+    tris = tris_random(rs, 1500, sc["extent"], sc["size"], sc["offset"])
+    origins = (rs.uniform(-1.5, 1.5, (64, 3)) * sc["extent"] + np.asarray(sc["offset"]))
+    o1, d1 = rays_through_features(rs, tris, origins, per_tri=3)
+    o1 = (o1 + d1 * f32(0.001)).astype(f32)
+    o2, d2 = bounce_like_rays(rs, tris, 3000, sc["extent"], sc["offset"])
+    o3, d3 = in_plane_rays(rs, tris, 3000, 4.0)
+    st = run_clustered(fm, tris, np.concatenate([o1, o2, o3]), np.concatenate([d1, d2, d3]))
+    assert st["bad"] == 0, st
+    assert st["accepts"] > 1000, st
+    if sc["name"] in ("soup", "tiny_scene", "large_scene"):
+        # small triangles in a large scene: the two sweeps leave little for the edge filter
+        assert st["unclustered"] < 0.02 * tris.shape[0], st
+        assert st["member"] < 0.02 * st["pairs"] and st["sphere"] < 0.3 * st["pairs"], st
+
+
+def test_clustered_path_in_plane_rays_far_from_their_triangle(fm):
+    """Coplanar rays up to 30 edge lengths away: the band + slab must keep every pair the
+    reference accepts out of rounding noise (there are such pairs: accepts counts them)."""
+    rs = np.random.RandomState(72)
+    tris = tris_random(rs, 800, 1.0, 0.1)
+    o, d = in_plane_rays(rs, tris, 20000, 30.0)
+    st = run_clustered(fm, tris, o, d)
+    assert st["bad"] == 0, st
+    assert st["accepts"] > 3000, st
+
+
+def test_clustered_path_nasty_triangles_and_coplanar_floor(fm):
+    rs = np.random.RandomState(73)
+    n = 600
+    xy = rs.uniform(-2, 2, (n, 3, 2))
+    floor = np.concatenate([xy, np.zeros((n, 3, 1))], axis=2).astype(f32)   # many coplanar triangles
+    tris = np.concatenate([tris_nasty(rs, 1500, 2.0), floor])
+    # rays skimming the floor plane, plus feature-aimed and bounce-like rays
+    o = np.concatenate([rs.uniform(-3, 3, (3000, 2)), 10.0 ** rs.uniform(-9, -2, (3000, 1)) * rs.choice([-1, 0, 1], (3000, 1))], axis=1)
+    d = np.concatenate([rs.normal(size=(3000, 2)), 10.0 ** rs.uniform(-9, -2, (3000, 1)) * rs.choice([-1, 0, 1], (3000, 1))], axis=1)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    o1, d1 = rays_through_features(rs, tris, rs.uniform(-4, 4, (64, 3)), per_tri=2)
+    o2, d2 = bounce_like_rays(rs, tris, 2000, 2.0, (0, 0, 0))
+    fin = np.isfinite(o2).all(1) & np.isfinite(d2).all(1)
+    st = run_clustered(fm, tris, np.concatenate([o.astype(f32), o1, o2[fin]]), np.concatenate([d.astype(f32), d1, d2[fin]]))
+    assert st["bad"] == 0, st
+    assert st["accepts"] > 1000, st
+
+
+def test_clustered_path_rays_outside_the_records_range(fm):
+    """Origins far outside the scene: the band, slab and sphere records do not apply, and every
+    pair of such a ray must go to the edge filter."""
+    rs = np.random.RandomState(74)
+    tris = tris_random(rs, 500, 1.0, 0.2)
+    far = rs.normal(size=(64, 3))
+    far = far / np.linalg.norm(far, axis=1, keepdims=True) * rs.uniform(20, 2000, (64, 1))
+    o, d = rays_through_features(rs, tris, far, per_tri=3)
+    st = run_clustered(fm, tris, o, d)
+    assert st["bad"] == 0, st
+    assert st["wild"] == o.shape[0] and st["accepts"] > 300, st
+    # and non-finite input never produces a wrong rejection
+    o[0] = np.nan; d[1] = 0.0; o[2, 1] = np.inf; d[3, 2] = np.nan
+    tris[0, 1] = tris[0, 0]; tris[1, 2, 0] = np.nan; tris[2, 1, 1] = np.inf
+    st = run_clustered(fm, tris, o, d)
+    assert st["bad"] == 0, st
+
+
+def test_clustered_path_room_with_walls_and_small_objects(fm):
+    """Two wall-sized triangles per side around small objects (the sword scene's shape): the walls
+    are too large to cluster and stay in every band; the small triangles are clustered."""
+    rs = np.random.RandomState(75)
+    small = tris_random(rs, 1200, 1.0, 0.05)
+    c = 3.0
+    quads = []
+    for axis in range(3):
+        for sgn in (-1, 1):
+            p = np.zeros((4, 3)); other = [a for a in range(3) if a != axis]
+            p[:, axis] = sgn * c
+            p[:, other[0]] = [-c, c, c, -c]; p[:, other[1]] = [-c, -c, c, c]
+            quads += [p[[0, 1, 2]], p[[0, 2, 3]]]
+    tris = np.concatenate([small, np.array(quads, dtype=f32)])
+    o1, d1 = bounce_like_rays(rs, tris, 4000, 1.0, (0, 0, 0))
+    o2, d2 = in_plane_rays(rs, tris, 4000, 2.0)
+    st = run_clustered(fm, tris, np.concatenate([o1, o2]), np.concatenate([d1, d2]))
+    assert st["bad"] == 0, st
+    assert 12 <= st["unclustered"] < 40, st
+    assert st["accepts"] > 3000, st
