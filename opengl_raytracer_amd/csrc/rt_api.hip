@@ -53,9 +53,7 @@ struct rt_ctx {
     size_t rec_stride = 0;
     // clustered traversal of arbitrary rays: plane bands per triangle, spheres / member records per cluster
     float4 *ngroup_d = nullptr;
-    float4 *nband_d = nullptr;
-    float2 *nslab_d = nullptr;
-    int *nmember_d = nullptr;
+    float4 *nrec_d = nullptr;
     int num_ngroups = 0;
     float4 *sphere_d = nullptr;
     rtf::TriRec *crec_d = nullptr;
@@ -292,9 +290,7 @@ extern "C" void rt_destroy(rt_ctx *c)
     (void)hipFree(c->cone_camera);
     (void)hipFree(c->cone_lights);
     (void)hipFree(c->ngroup_d);
-    (void)hipFree(c->nband_d);
-    (void)hipFree(c->nslab_d);
-    (void)hipFree(c->nmember_d);
+    (void)hipFree(c->nrec_d);
     (void)hipFree(c->sphere_d);
     (void)hipFree(c->crec_d);
     (void)hipFree(c->member_d);
@@ -326,9 +322,7 @@ extern "C" int rt_set_mesh(rt_ctx *c, const rt_vertex *vertices, int num_vertice
     (void)hipFree(c->cone_camera); c->cone_camera = nullptr;
     (void)hipFree(c->cone_lights); c->cone_lights = nullptr;
     (void)hipFree(c->ngroup_d); c->ngroup_d = nullptr;
-    (void)hipFree(c->nband_d); c->nband_d = nullptr;
-    (void)hipFree(c->nslab_d); c->nslab_d = nullptr;
-    (void)hipFree(c->nmember_d); c->nmember_d = nullptr;
+    (void)hipFree(c->nrec_d); c->nrec_d = nullptr;
     c->num_ngroups = 0;
     (void)hipFree(c->sphere_d); c->sphere_d = nullptr;
     (void)hipFree(c->crec_d); c->crec_d = nullptr;
@@ -397,19 +391,13 @@ extern "C" int rt_set_mesh(rt_ctx *c, const rt_vertex *vertices, int num_vertice
         c->num_ngroups = cs.num_ngroups;
         const size_t ng = (size_t)cs.num_ngroups, nc = (size_t)cs.num_clusters;
         HIPCHK(c, hipMalloc(&c->ngroup_d, (ng + 1) * sizeof(float4)));
-        HIPCHK(c, hipMalloc(&c->nband_d, (ng * rtc::NGROUP + 1) * sizeof(float4)));
-        HIPCHK(c, hipMalloc(&c->nslab_d, (ng * rtc::NGROUP + 1) * sizeof(float2)));
-        HIPCHK(c, hipMalloc(&c->nmember_d, (ng * rtc::NGROUP + 1) * sizeof(int)));
+        HIPCHK(c, hipMalloc(&c->nrec_d, (ng * rtc::NGROUP + 1) * 2 * sizeof(float4)));
         HIPCHK(c, hipMalloc(&c->sphere_d, (nc + 1) * sizeof(float4)));
         HIPCHK(c, hipMalloc(&c->crec_d, (nc * rtc::CLUSTER + 1) * sizeof(rtf::TriRec)));
         HIPCHK(c, hipMalloc(&c->member_d, (nc * rtc::CLUSTER + 1) * sizeof(int)));
         if (ng) {
             HIPCHK(c, hipMemcpyAsync(c->ngroup_d, cs.ngroups.data(), ng * sizeof(float4), hipMemcpyHostToDevice, c->stream));
-            HIPCHK(c, hipMemcpyAsync(c->nband_d, cs.nbands.data(), ng * rtc::NGROUP * sizeof(float4),
-                                     hipMemcpyHostToDevice, c->stream));
-            HIPCHK(c, hipMemcpyAsync(c->nslab_d, cs.nslabs.data(), ng * rtc::NGROUP * sizeof(float2),
-                                     hipMemcpyHostToDevice, c->stream));
-            HIPCHK(c, hipMemcpyAsync(c->nmember_d, cs.nmembers.data(), ng * rtc::NGROUP * sizeof(int),
+            HIPCHK(c, hipMemcpyAsync(c->nrec_d, cs.nrecs.data(), ng * rtc::NGROUP * 2 * sizeof(float4),
                                      hipMemcpyHostToDevice, c->stream));
         }
         if (nc) {
@@ -665,7 +653,8 @@ static int launch_traverse(rt_ctx *c, TraverseParams p, int n_upper, int form, b
 // The clustered closest-hit traversal of arbitrary rays (form 2 in the kernel log).
 static int launch_traverse_clustered(rt_ctx *c, TraverseParams p, int n_upper)
 {
-    const int k = pick_rays_per_lane(n_upper);
+    // 48 bytes of LDS per staged ray: two rays per lane keep four workgroups on a CU
+    const int k = n_upper >= 16384 ? 2 : 1;
     const int ray_blocks = cdiv(n_upper, BLOCK * k);
     const int tiles = cdiv(p.tri_end - p.tri_begin, TILE);
     if (ray_blocks <= 0 || tiles <= 0) return RT_OK;
@@ -673,9 +662,7 @@ static int launch_traverse_clustered(rt_ctx *c, TraverseParams p, int n_upper)
     p.tiles_per_y = (p.tiles_per_y + CONE_TILE / TILE - 1) / (CONE_TILE / TILE) * (CONE_TILE / TILE);
     const dim3 grid(ray_blocks, cdiv(tiles, p.tiles_per_y));
     p.ngroups = c->ngroup_d;
-    p.nbands = c->nband_d;
-    p.nslabs = c->nslab_d;
-    p.nmembers = c->nmember_d;
+    p.nrecs = c->nrec_d;
     p.num_ngroups = c->num_ngroups;
     p.spheres = c->sphere_d;
     p.crecs = c->crec_d;
@@ -685,8 +672,7 @@ static int launch_traverse_clustered(rt_ctx *c, TraverseParams p, int n_upper)
     if (int r = klog_begin(c, 1, 2, k, false, (unsigned long long)n_upper,
                            (unsigned long long)n_upper * (unsigned long long)(p.tri_end - p.tri_begin), &ks))
         return r;
-    if (k == 4) hipLaunchKernelGGL((traverse_cluster_kernel<4>), grid, dim3(BLOCK), 0, c->stream, p);
-    else if (k == 2) hipLaunchKernelGGL((traverse_cluster_kernel<2>), grid, dim3(BLOCK), 0, c->stream, p);
+    if (k == 2) hipLaunchKernelGGL((traverse_cluster_kernel<2>), grid, dim3(BLOCK), 0, c->stream, p);
     else hipLaunchKernelGGL((traverse_cluster_kernel<1>), grid, dim3(BLOCK), 0, c->stream, p);
     HIPCHK(c, hipGetLastError());
     return klog_end(c, ks);

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <vector>
 
 #include "../../include/rt.h"
@@ -33,6 +34,10 @@ struct ClusterSet {
     std::vector<rtf::BandRec> nbands;    // NGROUP per group: the member's own band record (theta = -1: padding)
     std::vector<rtf::SlabRec> nslabs;    // NGROUP per group: and its slab record
     std::vector<int32_t> nmembers;       // NGROUP per group: triangle index or -1
+    // the same three, as the kernel reads them: 8 floats per member,
+    //   (n/theta, kappa/H), (n/H, triangle index as bits)
+    // so that "in the band and in the slab" is  max(|n1.b|, |n2.o - kappa'|) < 1
+    std::vector<float> nrecs;
     int num_ngroups = 0;
 };
 
@@ -227,6 +232,26 @@ inline void build_normal_groups(ClusterSet &cs)
             cs.nmembers[b + (i - b)] = keyed[i];
         }
     }
+    auto pack = [&]() {
+        cs.nrecs.assign(cs.nmembers.size() * 8, 0.0f);
+        for (size_t i = 0; i < cs.nmembers.size(); i++) {
+            float *r = &cs.nrecs[i * 8];
+            const float *bnd = cs.nbands[i].v, *slb = cs.nslabs[i].v;
+            const int32_t tri = cs.nmembers[i];
+            memcpy(&r[7], &tri, 4);
+            if (tri < 0 || !(bnd[3] >= 0.0f)) {
+                r[3] = 2.0f; // |0 - 2| >= 1: never inside
+                continue;
+            }
+            const double down = 1.0 - 1e-6; // the divisions below round; stay on the wide side
+            if (bnd[3] < INFINITY)
+                for (int a = 0; a < 3; a++) r[a] = (float)((double)bnd[a] / (double)bnd[3] * down);
+            if (slb[1] < INFINITY) {
+                for (int a = 0; a < 3; a++) r[4 + a] = (float)((double)bnd[a] / (double)slb[1] * down);
+                r[3] = (float)((double)slb[0] / (double)slb[1] * down);
+            }
+        }
+    };
     for (int g = 0; g < g_alw; g++) {
         const size_t b = (size_t)g * NGROUP, e = std::min(always.size(), b + NGROUP);
         const size_t o = (size_t)(g_reg + g) * NGROUP;
@@ -237,6 +262,7 @@ inline void build_normal_groups(ClusterSet &cs)
             cs.nmembers[o + (i - b)] = always[i];
         }
     }
+    pack();
 }
 
 } // namespace rtc

@@ -378,9 +378,8 @@ struct TraverseParams {
     unsigned long long *counters;
     // clustered traversal of arbitrary rays (traverse_cluster_kernel) only
     const float4 *ngroups;      // one (axis, w) per group of triangles with similar normals
-    const float4 *nbands;       // the members' own (unit normal, theta), NGROUP per group; theta = -1: padding
-    const float2 *nslabs;       // and their (kappa, H): the origin must lie within H of the plane
-    const int *nmembers;        // triangle index of each of them, or -1
+    const float4 *nrecs;        // the members, two float4 each: (n/theta, kappa/H), (n/H, triangle index);
+                                // inside the member's band and slab <=> max(|n1.b|, |n2.o - kappa'|) < 1
     int num_ngroups;
     const float4 *spheres;      // one (centre, R^2) per cluster of triangles close in space
     const rtf::TriRec *crecs;   // the members' general edge records, CLUSTER per cluster
@@ -746,8 +745,8 @@ __global__ __launch_bounds__(BLOCK) void traverse_cluster_kernel(TraverseParams 
 {
     constexpr int NR = BLOCK * K;
     __shared__ float4 tile[GROUP_TILE];
-    __shared__ float rox[NR], roy[NR], roz[NR], rdx[NR], rdy[NR], rdz[NR], rg[NR];
-    __shared__ int rslot[NR];
+    // the workgroup's rays: (unit direction, |g|), (origin, slot), (direction * |g|, -)
+    __shared__ float4 ray_b[NR], ray_o[NR], ray_h[NR];
     __shared__ unsigned int queue_all[(BLOCK / 64) * qcap(1)];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -778,35 +777,40 @@ __global__ __launch_bounds__(BLOCK) void traverse_cluster_kernel(TraverseParams 
         }
         // outside the range the band records were built for: every band holds this ray
         wild[k] = valid[k] && !(g > 0.0f);
-        rox[r] = ox[k]; roy[r] = oy[k]; roz[r] = oz[k];
-        rdx[r] = dx; rdy[r] = dy; rdz[r] = dz;
-        rg[r] = fabsf(g);
-        rslot[r] = sl;
+        const float gg = fabsf(g);
+        ray_b[r] = make_float4(bx[k], by[k], bz[k], gg);
+        ray_o[r] = make_float4(ox[k], oy[k], oz[k], __int_as_float(sl));
+        ray_h[r] = make_float4(dx * gg, dy * gg, dz * gg, 0.0f);
     }
     unsigned long long wild_mask[K], valid_mask[K];
+    bool any_wild = false;
 #pragma unroll
     for (int k = 0; k < K; k++) {
         wild_mask[k] = __builtin_amdgcn_ballot_w64(wild[k]);
         valid_mask[k] = __builtin_amdgcn_ballot_w64(valid[k]);
+        any_wild = any_wild || wild_mask[k] != 0ull;
     }
 
     unsigned int *queue = queue_all + wave * qcap(1);
     int qcount = 0; // wave-uniform
     unsigned long long n_cand = 0, n_slow = 0;
 
-    // the reference arithmetic on one pair whose edge filter passed
+    // the reference arithmetic on one pair whose edge filter passed (rare: the direction comes
+    // from global memory)
     auto confirm = [&](int r, int tri) {
-        const v3 o = rtx::V(rox[r], roy[r], roz[r]), d = rtx::V(rdx[r], rdy[r], rdz[r]);
+        const float4 ro = ray_o[r];
+        const int sl = __float_as_int(ro.w);
+        const v3 o = rtx::V(ro.x, ro.y, ro.z), d = rtx::V(p.job.dx[sl], p.job.dy[sl], p.job.dz[sl]);
         const v3 X = vpos(p.verts, 3 * tri), Y = vpos(p.verts, 3 * tri + 1), Z = vpos(p.verts, 3 * tri + 2);
         float t;
         if (rtx::ray_vs_triangle(o, d, X, Y, Z, t) && t > 0.0f) {
             const unsigned long long key =
                 ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)(unsigned int)tri;
-            atomicMin(&p.best[rslot[r]], key);
+            atomicMin(&p.best[sl], key);
         }
     };
 
-    // sweep A's queue: (triangle, ray) pairs inside a plane band, one per lane
+    // sweep A's queue: (triangle, ray) pairs inside a plane band and slab, one per lane
     auto drain_pairs = [&](bool all) {
 #ifdef RT_DBG_NO_DRAIN
         qcount = 0;
@@ -821,12 +825,20 @@ __global__ __launch_bounds__(BLOCK) void traverse_cluster_kernel(TraverseParams 
                 const unsigned int e = queue[qcount + lane];
                 r = (int)(e & 2047u);
                 tri = (int)(e >> 11);
-                const float gg = rg[r];
-                pass = rtf::filter_general(reinterpret_cast<const float *>(p.recs + tri), rox[r], roy[r], roz[r],
-                                           rdx[r] * gg, rdy[r] * gg, rdz[r] * gg) >= -1.0f;
+                const float4 ro = ray_o[r], rh = ray_h[r];
+                pass = rtf::filter_general(reinterpret_cast<const float *>(p.recs + tri), ro.x, ro.y, ro.z, rh.x, rh.y,
+                                           rh.z) >= -1.0f;
             }
             n_cand += __popcll(__builtin_amdgcn_ballot_w64(pass));
             if (pass) confirm(r, tri);
+        }
+    };
+    auto push_pairs = [&](bool in, int tri, int r) {
+        const unsigned long long h = __builtin_amdgcn_ballot_w64(in);
+        if (h) {
+            if (in) queue[qcount + lanes_below(h)] = ((unsigned int)tri << 11) | (unsigned int)r;
+            qcount += __popcll(h);
+            if (qcount >= qcap(1) - 64) drain_pairs(false);
         }
     };
 
@@ -856,31 +868,42 @@ __global__ __launch_bounds__(BLOCK) void traverse_cluster_kernel(TraverseParams 
             }
             if (!any) continue;
             n_slow++;
-            // one lane per member: its own band record
-            const int idx = (tile_base + j) * NGROUP + lane;
-            const float4 mb = p.nbands[idx];
-            const float2 ms = p.nslabs[idx];
-            const int tri = p.nmembers[idx];
+            // one lane per member: (n/theta, kappa/H), (n/H, triangle)
+            const float4 *mr = p.nrecs + (size_t)((tile_base + j) * NGROUP + lane) * 2;
+            const float4 m1 = mr[0], m2 = mr[1];
+            const int tri = __float_as_int(m2.w);
 #pragma unroll
             for (int k = 0; k < K; k++) {
-                unsigned long long mk = m[k];
-                while (mk) {
-                    const int src = __builtin_ctzll(mk);
+                unsigned long long mk = m[k] & ~wild_mask[k];
+                const int rbase = (wave * K + k) * 64;
+                if (mk) {
+                    // the next ray's record is fetched while the current one is tested
+                    int src = __builtin_ctzll(mk);
                     mk &= mk - 1;
-                    const float rbx = readlane_f(bx[k], src), rby = readlane_f(by[k], src), rbz = readlane_f(bz[k], src);
-                    const float rox_ = readlane_f(ox[k], src), roy_ = readlane_f(oy[k], src), roz_ = readlane_f(oz[k], src);
-                    const float t = fabsf(fmaf(mb.z, rbz, fmaf(mb.y, rby, mb.x * rbx)));
-                    const float hgt = fabsf(fmaf(mb.z, roz_, fmaf(mb.y, roy_, mb.x * rox_)) - ms.x);
-                    const bool w = (wild_mask[k] >> src) & 1ull;
-                    const bool in = (((t < mb.w) && (hgt < ms.y)) || (w && mb.w >= 0.0f)) && tri >= 0;
-                    const unsigned long long h = __builtin_amdgcn_ballot_w64(in);
-                    if (h) {
-                        if (in)
-                            queue[qcount + lanes_below(h)] =
-                                ((unsigned int)tri << 11) | (unsigned int)((wave * K + k) * 64 + src);
-                        qcount += __popcll(h);
-                        if (qcount >= qcap(1) - 64) drain_pairs(false);
+                    float4 rb = ray_b[rbase + src], ro = ray_o[rbase + src];
+                    for (;;) {
+                        const bool more = mk != 0ull;
+                        int nsrc = 0;
+                        float4 nb = rb, no = ro;
+                        if (more) {
+                            nsrc = __builtin_ctzll(mk);
+                            mk &= mk - 1;
+                            nb = ray_b[rbase + nsrc];
+                            no = ray_o[rbase + nsrc];
+                        }
+                        const float t = fmaf(m1.z, rb.z, fmaf(m1.y, rb.y, m1.x * rb.x));
+                        const float h = fmaf(m2.z, ro.z, fmaf(m2.y, ro.y, fmaf(m2.x, ro.x, -m1.w)));
+                        push_pairs(fmaxf(fabsf(t), fabsf(h)) < 1.0f, tri, rbase + src);
+                        if (!more) break;
+                        src = nsrc; rb = nb; ro = no;
                     }
+                }
+                // rays outside the records' range: every member that can be accepted at all
+                unsigned long long wk = m[k] & wild_mask[k];
+                while (wk) {
+                    const int src = __builtin_ctzll(wk);
+                    wk &= wk - 1;
+                    push_pairs(tri >= 0 && m1.w != 2.0f, tri, rbase + src);
                 }
             }
         }
@@ -921,6 +944,7 @@ __global__ __launch_bounds__(BLOCK) void traverse_cluster_kernel(TraverseParams 
 #pragma unroll
             for (int k = 0; k < K; k++) {
                 unsigned long long mk = m[k];
+                const int rbase = (wave * K + k) * 64;
                 while (mk) {
                     // the lower half of the wavefront takes the lowest set bit, the upper half the next
                     const int s0b = __builtin_ctzll(mk);
@@ -932,12 +956,10 @@ __global__ __launch_bounds__(BLOCK) void traverse_cluster_kernel(TraverseParams 
                     }
                     const int src = (lane < 32) ? s0b : s1b;
                     bool pass = false;
-                    int r = 0;
-                    if (src >= 0 && tri >= 0) {
-                        r = (wave * K + k) * 64 + src;
-                        const float gg = rg[r];
-                        pass = rtf::filter_general(rec, rox[r], roy[r], roz[r], rdx[r] * gg, rdy[r] * gg, rdz[r] * gg) >= -1.0f;
-                    }
+                    const int r = rbase + (src < 0 ? 0 : src);
+                    const float4 ro = ray_o[r], rh = ray_h[r];
+                    if (src >= 0 && tri >= 0)
+                        pass = rtf::filter_general(rec, ro.x, ro.y, ro.z, rh.x, rh.y, rh.z) >= -1.0f;
                     n_cand += __popcll(__builtin_amdgcn_ballot_w64(pass));
                     if (pass) confirm(r, tri);
                 }
@@ -953,6 +975,7 @@ __global__ __launch_bounds__(BLOCK) void traverse_cluster_kernel(TraverseParams 
         const int mine = min(NR, n - s0);
         add_counter(p.counters, C_CH_PAIRS, (unsigned long long)mine * (unsigned long long)p.num_tris);
     }
+    (void)any_wild;
 }
 
 // ---------------------------------------------------------------------------

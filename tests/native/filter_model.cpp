@@ -182,10 +182,11 @@ extern "C" void fm_check_clustered(int n_tris, const float *verts, int n_rays, c
                 const float tg = fabsf(fmaf(G[2], bz, fmaf(G[1], by, G[0] * bx)));
                 if (tg < G[3] || wild) {
                     gp++;
-                    const float *mb = cs.nbands[gpos[k]].v, *ms = cs.nslabs[gpos[k]].v;
-                    const float t = fabsf(fmaf(mb[2], bz, fmaf(mb[1], by, mb[0] * bx)));
-                    const float hgt = fabsf(fmaf(mb[2], o[2], fmaf(mb[1], o[1], mb[0] * o[0])) - ms[0]);
-                    if (((t < mb[3]) && (hgt < ms[1])) || (wild && mb[3] >= 0.0f)) {
+                    const float *m = &cs.nrecs[(size_t)gpos[k] * 8];
+                    const float t = fmaf(m[2], bz, fmaf(m[1], by, m[0] * bx));
+                    const float hgt = fmaf(m[6], o[2], fmaf(m[5], o[1], fmaf(m[4], o[0], -m[3])));
+                    const bool inside = fmaxf(fabsf(t), fabsf(hgt)) < 1.0f;
+                    if (wild ? (m[3] != 2.0f) : inside) {
                         mp++;
                         rtf::TriRec rec;
                         rtf::make_general_rec(X, Y, Z, &rec);
