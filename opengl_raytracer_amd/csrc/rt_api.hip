@@ -50,6 +50,10 @@ struct rt_ctx {
     rtf::TriRec *rec_lights = nullptr; // RT_MAX_LIGHTS x rec_stride
     rtf::ConeRec *cone_camera = nullptr;
     rtf::ConeRec *cone_lights = nullptr; // RT_MAX_LIGHTS x rec_stride
+    rtf::ConeRec *ccone_camera = nullptr; // one per run of 32 slots
+    rtf::ConeRec *ccone_lights = nullptr; // RT_MAX_LIGHTS x rec_stride / 32
+    int *slot_d = nullptr;                // triangle in each slot of the shared-origin traversal's order
+    int num_slots = 0;
     size_t rec_stride = 0;
     // clustered traversal of arbitrary rays: plane bands per triangle, spheres / member records per cluster
     float4 *ngroup_d = nullptr;
@@ -289,6 +293,9 @@ extern "C" void rt_destroy(rt_ctx *c)
     (void)hipFree(c->rec_lights);
     (void)hipFree(c->cone_camera);
     (void)hipFree(c->cone_lights);
+    (void)hipFree(c->ccone_camera);
+    (void)hipFree(c->ccone_lights);
+    (void)hipFree(c->slot_d);
     (void)hipFree(c->ngroup_d);
     (void)hipFree(c->nrec_d);
     (void)hipFree(c->sphere_d);
@@ -321,6 +328,10 @@ extern "C" int rt_set_mesh(rt_ctx *c, const rt_vertex *vertices, int num_vertice
     (void)hipFree(c->rec_lights); c->rec_lights = nullptr;
     (void)hipFree(c->cone_camera); c->cone_camera = nullptr;
     (void)hipFree(c->cone_lights); c->cone_lights = nullptr;
+    (void)hipFree(c->ccone_camera); c->ccone_camera = nullptr;
+    (void)hipFree(c->ccone_lights); c->ccone_lights = nullptr;
+    (void)hipFree(c->slot_d); c->slot_d = nullptr;
+    c->num_slots = 0;
     (void)hipFree(c->ngroup_d); c->ngroup_d = nullptr;
     (void)hipFree(c->nrec_d); c->nrec_d = nullptr;
     c->num_ngroups = 0;
@@ -338,10 +349,6 @@ extern "C" int rt_set_mesh(rt_ctx *c, const rt_vertex *vertices, int num_vertice
         HIPCHK(c, hipMemcpyAsync(c->verts, vertices, (size_t)num_vertices * sizeof(rt_vertex), hipMemcpyHostToDevice,
                                  c->stream));
     HIPCHK(c, hipMalloc(&c->rec_general, c->rec_stride * sizeof(rtf::TriRec)));
-    HIPCHK(c, hipMalloc(&c->rec_camera, c->rec_stride * sizeof(rtf::TriRec)));
-    HIPCHK(c, hipMalloc(&c->rec_lights, RT_MAX_LIGHTS * c->rec_stride * sizeof(rtf::TriRec)));
-    HIPCHK(c, hipMalloc(&c->cone_camera, c->rec_stride * sizeof(rtf::ConeRec)));
-    HIPCHK(c, hipMalloc(&c->cone_lights, RT_MAX_LIGHTS * c->rec_stride * sizeof(rtf::ConeRec)));
     if (c->num_tris)
         hipLaunchKernelGGL(prep_general_kernel, dim3(cdiv(c->num_tris, BLOCK)), dim3(BLOCK), 0, c->stream, c->verts,
                            c->num_tris, c->rec_general);
@@ -390,6 +397,20 @@ extern "C" int rt_set_mesh(rt_ctx *c, const rt_vertex *vertices, int num_vertice
         c->num_clusters = cs.num_clusters;
         c->num_ngroups = cs.num_ngroups;
         const size_t ng = (size_t)cs.num_ngroups, nc = (size_t)cs.num_clusters;
+        // the shared-origin traversal's records live in slot order (a whole number of 1024-slot tiles)
+        c->num_slots = (int)cs.slots.size();
+        c->rec_stride = (size_t)c->num_slots + CONE_TILE;
+        HIPCHK(c, hipMalloc(&c->slot_d, (c->rec_stride) * sizeof(int)));
+        HIPCHK(c, hipMemsetAsync(c->slot_d, 0xff, c->rec_stride * sizeof(int), c->stream));
+        if (c->num_slots)
+            HIPCHK(c, hipMemcpyAsync(c->slot_d, cs.slots.data(), (size_t)c->num_slots * sizeof(int), hipMemcpyHostToDevice,
+                                     c->stream));
+        HIPCHK(c, hipMalloc(&c->rec_camera, c->rec_stride * sizeof(rtf::TriRec)));
+        HIPCHK(c, hipMalloc(&c->rec_lights, RT_MAX_LIGHTS * c->rec_stride * sizeof(rtf::TriRec)));
+        HIPCHK(c, hipMalloc(&c->cone_camera, c->rec_stride * sizeof(rtf::ConeRec)));
+        HIPCHK(c, hipMalloc(&c->cone_lights, RT_MAX_LIGHTS * c->rec_stride * sizeof(rtf::ConeRec)));
+        HIPCHK(c, hipMalloc(&c->ccone_camera, (c->rec_stride / 32 + 1) * sizeof(rtf::ConeRec)));
+        HIPCHK(c, hipMalloc(&c->ccone_lights, RT_MAX_LIGHTS * (c->rec_stride / 32 + 1) * sizeof(rtf::ConeRec)));
         HIPCHK(c, hipMalloc(&c->ngroup_d, (ng + 1) * sizeof(float4)));
         HIPCHK(c, hipMalloc(&c->nrec_d, (ng * rtc::NGROUP + 1) * 2 * sizeof(float4)));
         HIPCHK(c, hipMalloc(&c->sphere_d, (nc + 1) * sizeof(float4)));
@@ -680,11 +701,14 @@ static int launch_traverse_clustered(rt_ctx *c, TraverseParams p, int n_upper)
 
 static int refresh_camera_recs(rt_ctx *c)
 {
-    if (c->camera_recs_dirty && c->num_tris) {
-        hipLaunchKernelGGL(prep_origin_kernel, dim3(cdiv(c->num_tris, BLOCK)), dim3(BLOCK), 0, c->stream, c->verts,
-                           c->num_tris, c->cam.pos[0], c->cam.pos[1], c->cam.pos[2],
+    if (c->camera_recs_dirty && c->num_slots) {
+        hipLaunchKernelGGL(prep_origin_kernel, dim3(cdiv(c->num_slots, BLOCK)), dim3(BLOCK), 0, c->stream, c->verts,
+                           (const int *)c->slot_d, c->num_slots, c->cam.pos[0], c->cam.pos[1], c->cam.pos[2],
                            rtf::scene_extent(c->cam.pos, c->center, c->radius),
                            rtf::cone_reach_max(c->cam.pos, c->center, c->radius), c->rec_camera, c->cone_camera);
+        HIPCHK(c, hipGetLastError());
+        hipLaunchKernelGGL(cluster_cone_kernel, dim3(cdiv(c->num_slots / 32, BLOCK)), dim3(BLOCK), 0, c->stream,
+                           (const rtf::ConeRec *)c->cone_camera, c->num_slots / 32, c->ccone_camera);
         HIPCHK(c, hipGetLastError());
     }
     c->camera_recs_dirty = false;
@@ -693,14 +717,18 @@ static int refresh_camera_recs(rt_ctx *c)
 
 static int refresh_light_recs(rt_ctx *c)
 {
-    if (c->light_recs_dirty && c->num_tris) {
+    if (c->light_recs_dirty && c->num_slots) {
         for (int a = 0; a < c->num_lights; a++) {
-            hipLaunchKernelGGL(prep_origin_kernel, dim3(cdiv(c->num_tris, BLOCK)), dim3(BLOCK), 0, c->stream,
-                               c->verts, c->num_tris, c->lights[a].pos[0], c->lights[a].pos[1], c->lights[a].pos[2],
-                               rtf::scene_extent(c->lights[a].pos, c->center, c->radius),
+            hipLaunchKernelGGL(prep_origin_kernel, dim3(cdiv(c->num_slots, BLOCK)), dim3(BLOCK), 0, c->stream,
+                               c->verts, (const int *)c->slot_d, c->num_slots, c->lights[a].pos[0], c->lights[a].pos[1],
+                               c->lights[a].pos[2], rtf::scene_extent(c->lights[a].pos, c->center, c->radius),
                                rtf::cone_reach_max(c->lights[a].pos, c->center, c->radius),
                                c->rec_lights + (size_t)a * c->rec_stride,
                                c->cone_lights + (size_t)a * c->rec_stride);
+            HIPCHK(c, hipGetLastError());
+            hipLaunchKernelGGL(cluster_cone_kernel, dim3(cdiv(c->num_slots / 32, BLOCK)), dim3(BLOCK), 0, c->stream,
+                               (const rtf::ConeRec *)(c->cone_lights + (size_t)a * c->rec_stride), c->num_slots / 32,
+                               c->ccone_lights + (size_t)a * (c->rec_stride / 32 + 1));
             HIPCHK(c, hipGetLastError());
         }
     }
@@ -777,11 +805,15 @@ extern "C" int rt_intersect(rt_ctx *c)
             p.n = n_upper;
             p.recs = shared ? c->rec_camera : c->rec_general;
             p.cones = c->cone_camera;
+            const bool exact = c->trace_mode == RT_TRACE_EXACT;
+            // shared origin: the records are in slot order; the all-pairs mode walks the mesh itself
+            p.tri_of = (shared && !exact) ? c->slot_d : nullptr;
+            p.ccones = (shared && c->trace_mode == RT_TRACE_CLUSTERED) ? c->ccone_camera : nullptr;
             p.reach_max = (float)rtf::cone_reach_max(c->cam.pos, c->center, c->radius);
             p.dir_sign = 1.0f;
             memcpy(p.origin, c->cam.pos, sizeof p.origin);
             p.tri_begin = 0;
-            p.tri_end = c->num_tris;
+            p.tri_end = (shared && !exact) ? c->num_slots : c->num_tris;
             if (clustered) {
                 if (int r = launch_traverse_clustered(c, p, n_upper)) return r;
             } else if (int r = launch_traverse(c, p, n_upper, shared ? 1 : 0, false, 1)) {
@@ -833,7 +865,9 @@ extern "C" int rt_color(rt_ctx *c)
                 hipLaunchKernelGGL(color_begin_kernel, g0, dim3(BLOCK), 0, c->stream, c->rays, c->list, cnt0,
                                    c->scratch);
                 HIPCHK(c, hipGetLastError());
-                const int chunk = shadow_chunk_tris(c->num_tris);
+                const bool exact = c->trace_mode == RT_TRACE_EXACT;
+                const int n_trav = exact ? c->num_tris : c->num_slots; // slots, or triangles in the all-pairs mode
+                const int chunk = shadow_chunk_tris(n_trav);
                 for (int a = 0; a < c->num_lights; a++) {
                     hipLaunchKernelGGL(shadow_setup_kernel, g0, dim3(BLOCK), 0, c->stream, cnt0, c->scratch, c->job,
                                        c->lights[a].pos[0], c->lights[a].pos[1], c->lights[a].pos[2],
@@ -842,7 +876,7 @@ extern "C" int rt_color(rt_ctx *c)
                     const int *alist = nullptr; // nullptr: slots 0..n0-1
                     const int *acount = cnt0;
                     int pp = 0;
-                    for (int t0 = 0; t0 < c->num_tris; t0 += chunk) {
+                    for (int t0 = 0; t0 < n_trav; t0 += chunk) {
                         TraverseParams p{};
                         fill_traverse_common(c, p);
                         p.alist = alist;
@@ -850,13 +884,17 @@ extern "C" int rt_color(rt_ctx *c)
                         p.n = n0;
                         p.recs = c->rec_lights + (size_t)a * c->rec_stride;
                         p.cones = c->cone_lights + (size_t)a * c->rec_stride;
+                        p.tri_of = exact ? nullptr : c->slot_d;
+                        p.ccones = c->trace_mode == RT_TRACE_CLUSTERED
+                                       ? c->ccone_lights + (size_t)a * (c->rec_stride / 32 + 1)
+                                       : nullptr;
                         p.reach_max = (float)rtf::cone_reach_max(c->lights[a].pos, c->center, c->radius);
                         p.dir_sign = -1.0f;
                         memcpy(p.origin, c->lights[a].pos, sizeof p.origin);
                         p.tri_begin = t0;
-                        p.tri_end = (t0 + chunk < c->num_tris) ? t0 + chunk : c->num_tris;
+                        p.tri_end = (t0 + chunk < n_trav) ? t0 + chunk : n_trav;
                         if (int r = launch_traverse(c, p, n0, 1, true, 2)) return r;
-                        if (p.tri_end < c->num_tris) {
+                        if (p.tri_end < n_trav) {
                             // keep the rays that are still unoccluded for the next chunk
                             int *ocount = c->count_d + 2 + pp;
                             HIPCHK(c, hipMemsetAsync(ocount, 0, sizeof(int), c->stream));

@@ -38,6 +38,10 @@ struct ClusterSet {
     //   (n/theta, kappa/H), (n/H, triangle index as bits)
     // so that "in the band and in the slab" is  max(|n1.b|, |n2.o - kappa'|) < 1
     std::vector<float> nrecs;
+    // Order in which the shared-origin traversal visits the triangles: the clusters above, then
+    // every triangle that is in none of them in runs of CLUSTER, -1 where a run is short, padded
+    // with -1 to a whole number of 1024-record tiles.  Every triangle appears exactly once.
+    std::vector<int32_t> slots;
     int num_ngroups = 0;
 };
 
@@ -164,6 +168,32 @@ inline void build(const rt_vertex *v, int num_tris, const float center[3], float
         out.spheres[(size_t)c * 4 + 3] = r2;
     }
     build_normal_groups(out);
+
+    // Clusters are laid out with a large stride between neighbours in space, so that any
+    // contiguous part of the order (a chunk of the shadow traversal) samples the whole scene.
+    out.slots.assign(out.members.size(), -1);
+    {
+        const size_t nc = (size_t)out.num_clusters;
+        size_t stride = nc / 8 + 1;
+        auto gcd = [](size_t a, size_t b) { while (b) { size_t t = a % b; a = b; b = t; } return a; };
+        while (nc > 1 && gcd(stride, nc) != 1) stride++;
+        for (size_t j = 0; j < nc; j++) {
+            const size_t c = (j * stride) % nc;
+            std::copy(out.members.begin() + c * CLUSTER, out.members.begin() + (c + 1) * CLUSTER,
+                      out.slots.begin() + j * CLUSTER);
+        }
+    }
+    std::vector<char> seen((size_t)num_tris, 0);
+    for (int32_t t : out.members)
+        if (t >= 0) seen[t] = 1;
+    size_t run = 0;
+    for (int t = 0; t < num_tris; t++) {
+        if (seen[t]) continue;
+        out.slots.push_back(t);
+        run++;
+    }
+    (void)run;
+    while (out.slots.size() % 1024 != 0) out.slots.push_back(-1);
 }
 
 // Groups the triangles that have a band (theta >= 0) by normal direction.  Normals are folded onto

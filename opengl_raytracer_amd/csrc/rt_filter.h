@@ -331,6 +331,53 @@ RT_HD void make_cone_rec(const float X[3], const float Y[3], const float Z[3], c
     out->v[3] = t;
 }
 
+// A cone that contains the cones of a cluster of triangles: a direction that passes a member's
+// test (float dot product with the member's axis >= its threshold) passes this one.  Members
+// with threshold 2 (nothing passes) do not count; one member with threshold -2 (everything
+// passes) makes the cluster's cone "everything".
+//   member half-angle  th_k = acos(w_k / |a_k| - 2^-20)      (the float dot product, |b| != 1)
+//   cluster half-angle Th   = max_k(angle(A, a_k) + th_k) + 1e-6,   threshold = |A| cos(Th) - 2e-6
+RT_HD void make_cluster_cone(const ConeRec *m, int n, ConeRec *out)
+{
+    double ax[3] = {0.0, 0.0, 0.0};
+    int live = 0;
+    for (int k = 0; k < n; k++) {
+        const float w = m[k].v[3];
+        if (w >= 2.0f) continue;
+        if (!(w > -2.0f)) { cone_always(out); return; }
+        live++;
+        for (int i = 0; i < 3; i++) ax[i] += (double)m[k].v[i];
+    }
+    if (!live) { cone_never(out); return; }
+    const double al = sqrt(dot3d(ax, ax));
+    if (!(al > 1e-3 * live)) { cone_always(out); return; }
+    const float axf[3] = {(float)(ax[0] / al), (float)(ax[1] / al), (float)(ax[2] / al)};
+    const double a[3] = {(double)axf[0], (double)axf[1], (double)axf[2]};
+    const double an = sqrt(dot3d(a, a));
+    double big = 0.0;
+    for (int k = 0; k < n; k++) {
+        const float w = m[k].v[3];
+        if (w >= 2.0f) continue;
+        const double mk[3] = {(double)m[k].v[0], (double)m[k].v[1], (double)m[k].v[2]};
+        const double ml = sqrt(dot3d(mk, mk));
+        if (!(ml > 0.0)) { cone_always(out); return; }
+        double c = dot3d(mk, a) / (ml * an);
+        c = c > 1.0 ? 1.0 : (c < -1.0 ? -1.0 : c);
+        double ct = (double)w / ml - 9.5367431640625e-07; // 2^-20
+        if (!(ct > -1.0)) { cone_always(out); return; }
+        if (ct > 1.0) ct = 1.0;
+        const double ang = acos(c) + acos(ct);
+        if (ang > big) big = ang;
+    }
+    big += 1e-6;
+    if (!(big < 1.5)) { cone_always(out); return; }
+    const double thr = cos(big) * an - 2e-6;
+    out->v[0] = axf[0]; out->v[1] = axf[1]; out->v[2] = axf[2];
+    float t = (float)thr;
+    if ((double)t > thr) t = nextafterf(t, -2.0f);
+    out->v[3] = t;
+}
+
 // `reach` of a ray whose line passes through the shared origin O (see dir_scale): the
 // geometric part bounds |o - X| + (longest edge) and |X - O| for every vertex X inside the
 // bounding sphere (C, R); the last term covers the only errors that grow with the absolute

@@ -148,20 +148,40 @@ __global__ __launch_bounds__(BLOCK) void prep_general_kernel(const rt_vertex *__
     out[k] = r;
 }
 
-__global__ __launch_bounds__(BLOCK) void prep_origin_kernel(const rt_vertex *__restrict__ v, int num_tris,
+// Edge and cone records for origin O, in slot order: slot i holds triangle order[i], or nothing
+// (order[i] < 0: a record no ray passes).
+__global__ __launch_bounds__(BLOCK) void prep_origin_kernel(const rt_vertex *__restrict__ v,
+                                                            const int *__restrict__ order, int num_slots,
                                                             float ox, float oy, float oz, double extent,
                                                             double reach_max, rtf::TriRec *__restrict__ out,
                                                             rtf::ConeRec *__restrict__ cones)
 {
-    const int k = blockIdx.x * BLOCK + threadIdx.x;
-    if (k >= num_tris) return;
-    const float O[3] = {ox, oy, oz};
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= num_slots) return;
+    const int k = order[i];
     rtf::TriRec r;
-    rtf::make_origin_rec(v[3 * k].pos, v[3 * k + 1].pos, v[3 * k + 2].pos, O, &r);
-    out[k] = r;
     rtf::ConeRec c;
-    rtf::make_cone_rec(v[3 * k].pos, v[3 * k + 1].pos, v[3 * k + 2].pos, O, &r, extent, reach_max, &c);
-    cones[k] = c;
+    if (k < 0) {
+        rtf::nan_rec(&r);
+        rtf::cone_never(&c);
+    } else {
+        const float O[3] = {ox, oy, oz};
+        rtf::make_origin_rec(v[3 * k].pos, v[3 * k + 1].pos, v[3 * k + 2].pos, O, &r);
+        rtf::make_cone_rec(v[3 * k].pos, v[3 * k + 1].pos, v[3 * k + 2].pos, O, &r, extent, reach_max, &c);
+    }
+    out[i] = r;
+    cones[i] = c;
+}
+
+// One cone per run of 32 slots that contains the cones of its members.
+__global__ __launch_bounds__(BLOCK) void cluster_cone_kernel(const rtf::ConeRec *__restrict__ cones, int num_runs,
+                                                             rtf::ConeRec *__restrict__ out)
+{
+    const int c = blockIdx.x * BLOCK + threadIdx.x;
+    if (c >= num_runs) return;
+    rtf::ConeRec r;
+    rtf::make_cluster_cone(cones + (size_t)c * 32, 32, &r);
+    out[c] = r;
 }
 
 // ---------------------------------------------------------------------------
@@ -363,6 +383,8 @@ struct TraverseParams {
     int n;
     const rtf::TriRec *recs;
     const rtf::ConeRec *cones; // FORM 1 only
+    const rtf::ConeRec *ccones; // FORM 1: one cone per run of 32 slots, or nullptr (no skipping)
+    const int *tri_of;          // FORM 1: triangle in each slot (-1: none), or nullptr (slot = triangle)
     const rt_vertex *verts;
     int num_tris;
     int tri_begin, tri_end; // multiple of TILE / end of range
@@ -442,6 +464,7 @@ __global__ __launch_bounds__(BLOCK) void traverse_kernel(TraverseParams p)
     // FORM 0: tiles of 256 edge records (12 KiB).  FORM 1: tiles of 1024 cone records (16 KiB);
     // the edge records are only touched by the rare second level and stay in global memory.
     __shared__ float4 lds4[FORM == 1 ? CONE_TILE : TILE * 3];
+    __shared__ float4 run4[FORM == 1 ? CONE_TILE / 32 : 1]; // FORM 1: the cones of the tile's 32 runs
     constexpr int TSZ = (FORM == 1) ? CONE_TILE : TILE;
 
     const int tid = threadIdx.x;
@@ -553,15 +576,17 @@ __global__ __launch_bounds__(BLOCK) void traverse_kernel(TraverseParams p)
             if (lane < take) {
                 const unsigned int e = queue[qcount + lane];
                 const int r = (int)(e & 2047u);
-                tri = t_begin + (int)(e >> 11);
+                const int ci = t_begin + (int)(e >> 11); // slot
                 const int s = s0 + r;
                 sl = p.alist ? p.alist[s] : s;
                 // the edge filter on the unit direction, scaled (two-sided: the sign is irrelevant)
                 const float gg = fabsf(p.job.g[sl]);
                 float lo, hi;
-                rtf::filter_origin_lohi(reinterpret_cast<const float *>(p.recs + tri), p.job.bx[sl] * gg,
+                rtf::filter_origin_lohi(reinterpret_cast<const float *>(p.recs + ci), p.job.bx[sl] * gg,
                                         p.job.by[sl] * gg, p.job.bz[sl] * gg, lo, hi);
                 pass2 = fmaxf(lo, -hi) >= -1.0f;
+                tri = p.tri_of ? p.tri_of[ci] : ci;
+                pass2 = pass2 && tri >= 0;
             }
             n_cand += __popcll(__builtin_amdgcn_ballot_w64(pass2));
             if (pass2) {
@@ -598,8 +623,12 @@ __global__ __launch_bounds__(BLOCK) void traverse_kernel(TraverseParams p)
 #pragma unroll
             for (int i = 0; i < CONE_TILE / BLOCK; i++) {
                 const int e = i * BLOCK + tid;
-                lds4[e] = (e < tile_n && tile_base + e < p.num_tris) ? cs[tile_base + e]
-                                                                    : make_float4(0.0f, 0.0f, 0.0f, 2.0f);
+                const bool have = p.tri_of ? (e < tile_n) : (e < tile_n && tile_base + e < p.num_tris);
+                lds4[e] = have ? cs[tile_base + e] : make_float4(0.0f, 0.0f, 0.0f, 2.0f);
+            }
+            if (tid < CONE_TILE / 32) {
+                const float4 *rc = reinterpret_cast<const float4 *>(p.ccones);
+                run4[tid] = (rc && tid * 32 < tile_n) ? rc[tile_base / 32 + tid] : make_float4(0.0f, 0.0f, 0.0f, -2.0f);
             }
         } else {
             load_tile(lds4, p.recs, tile_base, p.num_tris, tid);
@@ -640,6 +669,17 @@ __global__ __launch_bounds__(BLOCK) void traverse_kernel(TraverseParams p)
             // four triangles per step so that their LDS reads are in flight together.  Pairs
             // inside the cone are queued; full batches of 64 are handled with all lanes busy.
             for (int j = 0; j < CONE_TILE; j += 4) {
+                if ((j & 31) == 0) {
+                    // a run of 32 slots none of whose cones can hold a ray of this wavefront is skipped
+                    const float4 rc = run4[j >> 5];
+                    float G = fmaf(rc.z, bz[0], fmaf(rc.y, by[0], rc.x * bx[0]));
+#pragma unroll
+                    for (int k = 1; k < K; k++) G = fmaxf(G, fmaf(rc.z, bz[k], fmaf(rc.y, by[k], rc.x * bx[k])));
+                    if (!(any64(G >= rc.w) || wave_wild)) {
+                        j += 28;
+                        continue;
+                    }
+                }
                 const float4 c0 = lds4[j], c1 = lds4[j + 1], c2 = lds4[j + 2], c3 = lds4[j + 3];
                 float t0[K], t1[K], t2[K], t3[K];
 #pragma unroll
@@ -687,8 +727,11 @@ __global__ __launch_bounds__(BLOCK) void traverse_kernel(TraverseParams p)
             if (ANYHIT) {
                 // results of drained batches live in global memory: refresh this lane's view
 #pragma unroll
-                for (int k = 0; k < K; k++)
+                for (int k = 0; k < K; k++) {
                     if (valid[k] && !occ[k]) occ[k] = p.occ[slot[k]] != 0;
+                    // a decided ray no longer takes part: with a NaN direction it is in no cone
+                    if (occ[k]) bx[k] = qn;
+                }
             }
         }
     }
@@ -701,7 +744,7 @@ __global__ __launch_bounds__(BLOCK) void traverse_kernel(TraverseParams p)
     if (tid == 0) {
         const int mine = min(BLOCK * K, n - s0);
         add_counter(p.counters, ANYHIT ? C_SH_PAIRS : C_CH_PAIRS,
-                    (unsigned long long)mine * (unsigned long long)min(tris_done, p.num_tris - t_begin));
+                    (unsigned long long)mine * (unsigned long long)max(min(tris_done, p.num_tris - t_begin), 0));
     }
 
 #pragma unroll
