@@ -211,3 +211,50 @@ extern "C" void fm_check_clustered(int n_tris, const float *verts, int n_rays, c
     stats[0] = pairs; stats[1] = gp; stats[2] = mp; stats[3] = sp; stats[4] = reach_exact; stats[5] = acc;
     stats[6] = bad; stats[7] = wildn; stats[8] = noclu; stats[9] = never;
 }
+
+// Cone of a run of 32 triangles (rt_filter.h make_cluster_cone) against the cones of its members:
+// whenever a member's float test passes for a direction, the run's test must pass too.
+// stats: [0] (ray, run) pairs [1] run passes [2] (ray, member) passes [3] violations
+//        [4] runs whose cone is "everything" [5] runs whose cone is "nothing"
+extern "C" void fm_check_cluster_cone(int n_tris, const float *verts, int n_rays, const float *O, const float *dir,
+                                      const float *center, float radius, float sign, long long *stats)
+{
+    const double extent = rtf::scene_extent(O, center, radius);
+    const double rmax = rtf::cone_reach_max(O, center, radius);
+    const int runs = (n_tris + 31) / 32;
+    std::vector<rtf::ConeRec> cones((size_t)runs * 32), rc(runs);
+    for (int k = 0; k < runs * 32; k++) {
+        if (k >= n_tris) { rtf::cone_never(&cones[k]); continue; }
+        const float *X = verts + 9 * k, *Y = X + 3, *Z = X + 6;
+        rtf::TriRec rec;
+        rtf::make_origin_rec(X, Y, Z, O, &rec);
+        rtf::make_cone_rec(X, Y, Z, O, &rec, extent, rmax, &cones[k]);
+    }
+    long long all = 0, never = 0;
+    for (int c = 0; c < runs; c++) {
+        rtf::make_cluster_cone(&cones[(size_t)c * 32], 32, &rc[c]);
+        all += rc[c].v[3] == -2.0f;
+        never += rc[c].v[3] == 2.0f;
+    }
+    long long pairs = 0, rp = 0, mp = 0, bad = 0;
+#pragma omp parallel for reduction(+ : pairs, rp, mp, bad) schedule(static)
+    for (int i = 0; i < n_rays; i++) {
+        const float *d = dir + 3 * i;
+        const float inv = sign / sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        const float bx = d[0] * inv, by = d[1] * inv, bz = d[2] * inv;
+        for (int c = 0; c < runs; c++) {
+            const float tr = fmaf(rc[c].v[2], bz, fmaf(rc[c].v[1], by, rc[c].v[0] * bx));
+            const bool run_pass = tr >= rc[c].v[3];
+            pairs++;
+            rp += run_pass;
+            for (int j = 0; j < 32; j++) {
+                const rtf::ConeRec &m = cones[(size_t)c * 32 + j];
+                const float t = fmaf(m.v[2], bz, fmaf(m.v[1], by, m.v[0] * bx));
+                const bool in = (t >= m.v[3]) && (m.v[3] < 2.0f);
+                mp += in;
+                bad += (in && !run_pass);
+            }
+        }
+    }
+    stats[0] = pairs; stats[1] = rp; stats[2] = mp; stats[3] = bad; stats[4] = all; stats[5] = never;
+}

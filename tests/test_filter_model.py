@@ -468,3 +468,53 @@ def test_clustered_path_room_with_walls_and_small_objects(fm):
     assert st["bad"] == 0, st
     assert 12 <= st["unclustered"] < 40, st
     assert st["accepts"] > 3000, st
+
+
+# -- cones of runs of 32 slots (the run skip of the shared-origin traversal) ---------------------
+def run_cluster_cone(fm, tris, O, dirs, sign):
+    c, r = bounding_sphere(tris)
+    stats = (C.c_longlong * 6)()
+    tris = np.ascontiguousarray(tris, dtype=f32)
+    O = np.ascontiguousarray(O, dtype=f32)
+    dirs = np.ascontiguousarray(dirs, dtype=f32)
+    fm.fm_check_cluster_cone.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
+                                         C.c_float, C.c_void_p]
+    fm.fm_check_cluster_cone(tris.shape[0], tris.ctypes.data, dirs.shape[0], O.ctypes.data, dirs.ctypes.data,
+                             c.ctypes.data, r, sign, stats)
+    return dict(zip(["pairs", "run", "member", "bad", "everything", "nothing"], list(stats)))
+
+
+def spatially_sorted(tris):
+    """Runs of 32 are compact in space when the triangles are sorted along a curve."""
+    c = tris.astype(np.float64).mean(1)
+    q = ((c - c.min(0)) / (np.ptp(c, axis=0) + 1e-300) * 15).astype(int)
+    return tris[np.lexsort((q[:, 2], q[:, 1], q[:, 0]))]
+
+
+@pytest.mark.parametrize("sc", SCENES, ids=[s["name"] for s in SCENES])
+def test_run_cones_contain_their_members(fm, sc):
+    rs = np.random.RandomState(81)
+    tris = spatially_sorted(tris_random(rs, 2048, sc["extent"], sc["size"], sc["offset"]))
+    for trial in range(3):
+        O = (rs.uniform(-3, 3, 3) * sc["extent"] + np.asarray(sc["offset"])).astype(f32)
+        _, dirs = rays_through_features(rs, tris, O[None, :].astype(np.float64), per_tri=2)
+        # directions just outside and just inside member cones matter most: aim at the features
+        # and jitter by 1e-7 .. 1e-2
+        jit = dirs + rs.normal(size=dirs.shape).astype(f32) * (10.0 ** rs.uniform(-7, -2, (dirs.shape[0], 1))).astype(f32)
+        for sign in (1.0, -1.0):
+            st = run_cluster_cone(fm, tris, O, np.concatenate([dirs, jit]) * f32(sign), sign)
+            assert st["bad"] == 0, st
+            assert st["member"] > 1000, st
+            if sc["name"] == "soup":
+                assert st["run"] < 0.9 * st["pairs"] and st["everything"] < 0.1 * (tris.shape[0] // 32), st
+
+
+def test_run_cones_with_degenerate_always_and_unsorted_members(fm):
+    rs = np.random.RandomState(82)
+    tris = tris_nasty(rs, 1024, 2.0)           # unsorted: runs span the scene, many cones fall back to "everything"
+    O = f32([0.2, -0.1, 0.4])
+    tris[5, 0] = O                             # a vertex at the origin: that member's cone is "everything"
+    _, dirs = rays_through_features(rs, tris, O[None, :].astype(np.float64), per_tri=3)
+    fin = np.isfinite(dirs).all(1)
+    st = run_cluster_cone(fm, tris, O, dirs[fin], 1.0)
+    assert st["bad"] == 0 and st["everything"] >= 1, st
