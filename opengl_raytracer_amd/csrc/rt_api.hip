@@ -9,9 +9,12 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
+
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include "../../include/rt.h"
 #include "rt_kernels.h"
@@ -81,6 +84,11 @@ struct rt_ctx {
 
     int *list = nullptr;    // compacted ray indices (live rays / rays with a finite origin)
     int *alist[2] = {nullptr, nullptr}; // shadow rays still unoccluded (slots), ping-pong
+    // shadow rays sorted by the direction in which they leave the light
+    unsigned int *sort_keys = nullptr, *sort_keys_out = nullptr;
+    int *sort_iota = nullptr, *sort_slots = nullptr;
+    void *sort_temp = nullptr;
+    size_t sort_temp_bytes = 0;
     int *count_d = nullptr; // [0] intersect list, [1] shade list, [2],[3] alist sizes
     int *count_h = nullptr; // pinned
     float *work = nullptr;  // per-slot planes behind job / scratch
@@ -227,6 +235,18 @@ extern "C" int rt_create(rt_ctx **out, int hip_device, int width, int height)
     CRCHK(hipMalloc(&c->list, c->cap * sizeof(int)));
     CRCHK(hipMalloc(&c->alist[0], c->cap * sizeof(int)));
     CRCHK(hipMalloc(&c->alist[1], c->cap * sizeof(int)));
+    CRCHK(hipMalloc(&c->sort_keys, c->cap * sizeof(unsigned int)));
+    CRCHK(hipMalloc(&c->sort_keys_out, c->cap * sizeof(unsigned int)));
+    CRCHK(hipMalloc(&c->sort_iota, c->cap * sizeof(int)));
+    CRCHK(hipMalloc(&c->sort_slots, c->cap * sizeof(int)));
+    {
+        std::vector<int> iota(c->cap);
+        for (size_t i = 0; i < c->cap; i++) iota[i] = (int)i;
+        CRCHK(hipMemcpy(c->sort_iota, iota.data(), c->cap * sizeof(int), hipMemcpyHostToDevice));
+        CRCHK(rocprim::radix_sort_pairs(nullptr, c->sort_temp_bytes, c->sort_keys, c->sort_keys_out, c->sort_iota,
+                                        c->sort_slots, c->cap, 0, 20));
+        CRCHK(hipMalloc(&c->sort_temp, c->sort_temp_bytes + 256));
+    }
     {
         // 7 + 4 job planes + 6 float scratch planes + lit + occ + best (two words per slot)
         const size_t planes = 7 + 4 + 6 + 1 + 1 + 2;
@@ -305,6 +325,11 @@ extern "C" void rt_destroy(rt_ctx *c)
     (void)hipFree(c->list);
     (void)hipFree(c->alist[0]);
     (void)hipFree(c->alist[1]);
+    (void)hipFree(c->sort_keys);
+    (void)hipFree(c->sort_keys_out);
+    (void)hipFree(c->sort_iota);
+    (void)hipFree(c->sort_slots);
+    (void)hipFree(c->sort_temp);
     (void)hipFree(c->work);
     (void)hipFree(c->count_d);
     if (c->count_h) (void)hipHostFree(c->count_h);
@@ -833,7 +858,8 @@ extern "C" int rt_intersect(rt_ctx *c)
 // triangles per shadow chunk: rays found occluded in one chunk are dropped before the next
 static int shadow_chunk_tris(int num_tris)
 {
-    int chunk = (num_tris + 7) / 8;
+    static const int parts = getenv("RT_SHADOW_CHUNKS") ? atoi(getenv("RT_SHADOW_CHUNKS")) : 2;
+    int chunk = (num_tris + parts - 1) / parts;
     if (chunk < 4096) chunk = 4096;
     return (chunk + CONE_TILE - 1) / CONE_TILE * CONE_TILE;
 }
@@ -869,11 +895,21 @@ extern "C" int rt_color(rt_ctx *c)
                 const int n_trav = exact ? c->num_tris : c->num_slots; // slots, or triangles in the all-pairs mode
                 const int chunk = shadow_chunk_tris(n_trav);
                 for (int a = 0; a < c->num_lights; a++) {
+                    // in the clustered mode the shadow rays are visited in the order of the direction in
+                    // which they leave the light (any order gives the same result)
+                    const bool sorted = c->trace_mode == RT_TRACE_CLUSTERED && n0 >= 131072 && c->num_slots >= 8192;
                     hipLaunchKernelGGL(shadow_setup_kernel, g0, dim3(BLOCK), 0, c->stream, cnt0, c->scratch, c->job,
                                        c->lights[a].pos[0], c->lights[a].pos[1], c->lights[a].pos[2],
-                                       shared_origin(c, c->lights[a].pos, -1.0f), c->counters_d);
+                                       shared_origin(c, c->lights[a].pos, -1.0f), c->counters_d,
+                                       sorted ? c->sort_keys : (unsigned int *)nullptr);
                     HIPCHK(c, hipGetLastError());
                     const int *alist = nullptr; // nullptr: slots 0..n0-1
+                    if (sorted) {
+                        size_t bytes = c->sort_temp_bytes;
+                        HIPCHK(c, rocprim::radix_sort_pairs(c->sort_temp, bytes, c->sort_keys, c->sort_keys_out,
+                                                            c->sort_iota, c->sort_slots, (size_t)n0, 0, 20, c->stream));
+                        alist = c->sort_slots;
+                    }
                     const int *acount = cnt0;
                     int pp = 0;
                     for (int t0 = 0; t0 < n_trav; t0 += chunk) {

@@ -567,6 +567,13 @@ __global__ __launch_bounds__(BLOCK) void traverse_kernel(TraverseParams p)
         qcount = 0;
         return;
 #endif
+#ifdef RT_DBG_NO_DRAIN_ANYHIT
+        if (ANYHIT) {
+            n_cand += qcount;
+            qcount = 0;
+            return;
+        }
+#endif
         while (qcount >= 64 || (all && qcount > 0)) {
             const int take = qcount >= 64 ? 64 : qcount;
             qcount -= take;
@@ -679,6 +686,9 @@ __global__ __launch_bounds__(BLOCK) void traverse_kernel(TraverseParams p)
                         j += 28;
                         continue;
                     }
+#ifdef RT_DBG_COUNT_RUNS
+                    n_slow += 1000000;
+#endif
                 }
                 const float4 c0 = lds4[j], c1 = lds4[j + 1], c2 = lds4[j + 2], c3 = lds4[j + 3];
                 float t0[K], t1[K], t2[K], t3[K];
@@ -1106,9 +1116,34 @@ __global__ __launch_bounds__(BLOCK) void color_begin_kernel(RaySoA r, const int 
 }
 
 // raycol_cs.glsl:39-47
+// 20-bit sort key of a unit direction: octahedral map to the unit square, 10 bits per axis,
+// interleaved.  Shadow rays sorted by this key reach the traversal in wavefronts whose rays
+// leave the light in nearly the same direction, so that whole runs of triangles can be skipped.
+__device__ __forceinline__ unsigned int direction_key(float x, float y, float z)
+{
+    const float l1 = fabsf(x) + fabsf(y) + fabsf(z);
+    if (!(l1 > 0.0f) || !(l1 < INFINITY)) return 0xfffffu; // NaN / zero directions last
+    float u = x / l1, v = y / l1;
+    if (z < 0.0f) {
+        const float uu = (1.0f - fabsf(v)) * (u >= 0.0f ? 1.0f : -1.0f);
+        const float vv = (1.0f - fabsf(u)) * (v >= 0.0f ? 1.0f : -1.0f);
+        u = uu; v = vv;
+    }
+    unsigned int qu = (unsigned int)fminf(fmaxf((u * 0.5f + 0.5f) * 1023.0f, 0.0f), 1023.0f);
+    unsigned int qv = (unsigned int)fminf(fmaxf((v * 0.5f + 0.5f) * 1023.0f, 0.0f), 1023.0f);
+    auto spread = [](unsigned int a) {
+        a = (a | (a << 8)) & 0x00FF00FFu;
+        a = (a | (a << 4)) & 0x0F0F0F0Fu;
+        a = (a | (a << 2)) & 0x33333333u;
+        a = (a | (a << 1)) & 0x55555555u;
+        return a;
+    };
+    return spread(qu) | (spread(qv) << 1);
+}
+
 __global__ __launch_bounds__(BLOCK) void shadow_setup_kernel(const int *__restrict__ count, Scratch s, Job job,
                                                              float lx, float ly, float lz, SharedOrigin so,
-                                                             unsigned long long *counters)
+                                                             unsigned long long *counters, unsigned int *keys)
 {
     const int n = *count;
     const int slot = blockIdx.x * BLOCK + threadIdx.x;
@@ -1126,6 +1161,7 @@ __global__ __launch_bounds__(BLOCK) void shadow_setup_kernel(const int *__restri
     job.tmax[slot] = dist;
     s.occ[slot] = (dist < INFINITY) ? 0 : 1; // `lightRay.t > d` can only hold for finite d
     prepare_shared(job, slot, o2, ld, so.origin, so.center, so.radius, so.reach_max, so.sign);
+    if (keys) keys[slot] = direction_key(ld.x, ld.y, ld.z);
 }
 
 // spheres of the shadow trace, then raycol_cs.glsl:50-79 for the rays that reach the light
