@@ -715,10 +715,21 @@ __global__ __launch_bounds__(BLOCK) void traverse_kernel(TraverseParams p)
                         const bool hu = (u == 0) ? h0 : (u == 1) ? h1 : (u == 2) ? h2 : h3;
                         if (!(any64(hu) || wave_wild)) continue;
                         const unsigned int trel = (unsigned int)(tile_base + j + u - t_begin);
+                        // the triangle's edge record, read once for the wavefront: rays inside the cone
+                        // are queued only if they also pass the edge filter
+                        const float4 *er4 = reinterpret_cast<const float4 *>(p.recs + (tile_base + j + u));
+                        const float4 e0 = er4[0], e1 = er4[1], e2 = er4[2];
+                        const float er[12] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w, e2.x, e2.y, e2.z, e2.w};
 #pragma unroll
                         for (int k = 0; k < K; k++) {
                             const float t = (u == 0) ? t0[k] : (u == 1) ? t1[k] : (u == 2) ? t2[k] : t3[k];
-                            const bool in = ((t >= w) || wild[k]) && (w < 2.0f) && !occ[k];
+                            bool in = ((t >= w) || wild[k]) && (w < 2.0f) && !occ[k];
+                            if (any64(in)) {
+                                const float gg = fabsf(g[k]);
+                                float lo, hi;
+                                rtf::filter_origin_lohi(er, bx[k] * gg, by[k] * gg, bz[k] * gg, lo, hi);
+                                in = in && (fmaxf(lo, -hi) >= -1.0f);
+                            }
                             const unsigned long long m = __builtin_amdgcn_ballot_w64(in);
                             if (m) {
                                 if (in)
