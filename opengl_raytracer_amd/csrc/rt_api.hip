@@ -696,17 +696,12 @@ static int launch_traverse(rt_ctx *c, TraverseParams p, int n_upper, int form, b
     return klog_end(c, ks);
 }
 
-// The clustered closest-hit traversal of arbitrary rays (form 2 in the kernel log).
-static int launch_traverse_clustered(rt_ctx *c, TraverseParams p, int n_upper)
+// The clustered closest-hit traversal of arbitrary rays (form 2 in the kernel log).  Large launches
+// run the two sweeps as two kernels over two orders of the same rays: the band sweep over rays sorted
+// by direction (a wavefront's rays then share the few groups whose band holds them), the sphere sweep
+// over the pixel-tile order (its rays pass the same clusters).  Both merge into `best` by atomicMin.
+static int launch_traverse_clustered(rt_ctx *c, TraverseParams p, int n_upper, bool sorted)
 {
-    // 48 bytes of LDS per staged ray: two rays per lane keep four workgroups on a CU
-    const int k = n_upper >= 16384 ? 2 : 1;
-    const int ray_blocks = cdiv(n_upper, BLOCK * k);
-    const int tiles = cdiv(p.tri_end - p.tri_begin, TILE);
-    if (ray_blocks <= 0 || tiles <= 0) return RT_OK;
-    p.tiles_per_y = pick_tiles_per_y(ray_blocks, tiles);
-    p.tiles_per_y = (p.tiles_per_y + CONE_TILE / TILE - 1) / (CONE_TILE / TILE) * (CONE_TILE / TILE);
-    const dim3 grid(ray_blocks, cdiv(tiles, p.tiles_per_y));
     p.ngroups = c->ngroup_d;
     p.nrecs = c->nrec_d;
     p.num_ngroups = c->num_ngroups;
@@ -714,9 +709,40 @@ static int launch_traverse_clustered(rt_ctx *c, TraverseParams p, int n_upper)
     p.crecs = c->crec_d;
     p.members = c->member_d;
     p.num_clusters = c->num_clusters;
+    const int tiles = cdiv(p.tri_end - p.tri_begin, TILE);
+    if (n_upper <= 0 || tiles <= 0) return RT_OK;
     size_t ks;
+    if (sorted) {
+        {
+            TraverseParams a = p;
+            a.alist = c->sort_slots;
+            a.count = nullptr;
+            a.n = n_upper;
+            const int k = 4;
+            const int ray_blocks = cdiv(n_upper, BLOCK * k);
+            int want_y = (2048 + ray_blocks - 1) / ray_blocks;
+            const int max_y = cdiv(c->num_ngroups, BAND_TILE_GROUPS);
+            if (want_y > max_y) want_y = max_y;
+            if (want_y < 1) want_y = 1;
+            if (int r = klog_begin(c, 1, 2, k, false, (unsigned long long)n_upper,
+                                   (unsigned long long)n_upper * (unsigned long long)(p.tri_end - p.tri_begin), &ks))
+                return r;
+            hipLaunchKernelGGL((traverse_band_kernel<4>), dim3(ray_blocks, want_y), dim3(BLOCK), 0, c->stream, a);
+            HIPCHK(c, hipGetLastError());
+            if (int r = klog_end(c, ks)) return r;
+        }
+        p.sweeps = 2;
+    } else {
+        p.sweeps = 3;
+    }
+    // 48 bytes of LDS per staged ray: two rays per lane keep four workgroups on a CU
+    const int k = n_upper >= 16384 ? 2 : 1;
+    const int ray_blocks = cdiv(n_upper, BLOCK * k);
+    p.tiles_per_y = pick_tiles_per_y(ray_blocks, tiles);
+    p.tiles_per_y = (p.tiles_per_y + CONE_TILE / TILE - 1) / (CONE_TILE / TILE) * (CONE_TILE / TILE);
+    const dim3 grid(ray_blocks, cdiv(tiles, p.tiles_per_y));
     if (int r = klog_begin(c, 1, 2, k, false, (unsigned long long)n_upper,
-                           (unsigned long long)n_upper * (unsigned long long)(p.tri_end - p.tri_begin), &ks))
+                           sorted ? 0ull : (unsigned long long)n_upper * (unsigned long long)(p.tri_end - p.tri_begin), &ks))
         return r;
     if (k == 2) hipLaunchKernelGGL((traverse_cluster_kernel<2>), grid, dim3(BLOCK), 0, c->stream, p);
     else hipLaunchKernelGGL((traverse_cluster_kernel<1>), grid, dim3(BLOCK), 0, c->stream, p);
@@ -819,10 +845,16 @@ extern "C" int rt_intersect(rt_ctx *c)
         }
         if (n_upper > 0) {
             const bool clustered = !shared && c->trace_mode == RT_TRACE_CLUSTERED;
+            const bool sorted = clustered && n_upper >= 131072 && c->num_ngroups >= 64;
             hipLaunchKernelGGL(intersect_setup_kernel, dim3(cdiv(n_upper, BLOCK)), dim3(BLOCK), 0, c->stream, c->rays,
                                list, count, n_upper, c->job, c->scratch.best, shared ? 1 : (clustered ? 2 : 0),
-                               shared_origin(c, c->cam.pos, 1.0f));
+                               shared_origin(c, c->cam.pos, 1.0f), sorted ? c->sort_keys : (unsigned int *)nullptr);
             HIPCHK(c, hipGetLastError());
+            if (sorted) {
+                size_t bytes = c->sort_temp_bytes;
+                HIPCHK(c, rocprim::radix_sort_pairs(c->sort_temp, bytes, c->sort_keys, c->sort_keys_out, c->sort_iota,
+                                                    c->sort_slots, (size_t)n_upper, 0, 20, c->stream));
+            }
             TraverseParams p{};
             fill_traverse_common(c, p);
             p.alist = nullptr;
@@ -840,7 +872,7 @@ extern "C" int rt_intersect(rt_ctx *c)
             p.tri_begin = 0;
             p.tri_end = (shared && !exact) ? c->num_slots : c->num_tris;
             if (clustered) {
-                if (int r = launch_traverse_clustered(c, p, n_upper)) return r;
+                if (int r = launch_traverse_clustered(c, p, n_upper, sorted)) return r;
             } else if (int r = launch_traverse(c, p, n_upper, shared ? 1 : 0, false, 1)) {
                 return r;
             }

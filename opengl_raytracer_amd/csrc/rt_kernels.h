@@ -337,10 +337,12 @@ __device__ __forceinline__ v3 vpos(const rt_vertex *__restrict__ v, int i)
 // ---------------------------------------------------------------------------
 // intersect, part 1 of 3  ("OpenGL Raytracer/rayintersect_cs.glsl":6-12)
 // ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned int direction_key(float x, float y, float z);
+
 __global__ __launch_bounds__(BLOCK) void intersect_setup_kernel(RaySoA r, const int *__restrict__ list,
                                                                 const int *__restrict__ count, int n_fixed, Job job,
                                                                 unsigned long long *__restrict__ best, int shared,
-                                                                SharedOrigin so)
+                                                                SharedOrigin so, unsigned int *keys)
 {
     const int n = count ? *count : n_fixed;
     const int slot = blockIdx.x * BLOCK + threadIdx.x;
@@ -354,6 +356,11 @@ __global__ __launch_bounds__(BLOCK) void intersect_setup_kernel(RaySoA r, const 
     best[slot] = BEST_NONE;
     if (shared == 1) prepare_shared(job, slot, o, d, so.origin, so.center, so.radius, so.reach_max, so.sign);
     if (shared == 2) prepare_general(job, slot, o, d, so.center, so.radius);
+    if (keys) {
+        // the band test does not see the sign of the direction: fold onto one hemisphere
+        const float sg = (d.z < 0.0f || (d.z == 0.0f && (d.y < 0.0f || (d.y == 0.0f && d.x < 0.0f)))) ? -1.0f : 1.0f;
+        keys[slot] = direction_key(d.x * sg, d.y * sg, d.z * sg);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -399,6 +406,7 @@ struct TraverseParams {
     int *occ;
     unsigned long long *counters;
     // clustered traversal of arbitrary rays (traverse_cluster_kernel) only
+    int sweeps;                 // traverse_cluster_kernel: bit 0 = sweep A (bands), bit 1 = sweep B (spheres)
     const float4 *ngroups;      // one (axis, w) per group of triangles with similar normals
     const float4 *nrecs;        // the members, two float4 each: (n/theta, kappa/H), (n/H, triangle index);
                                 // inside the member's band and slab <=> max(|n1.b|, |n2.o - kappa'|) < 1
@@ -912,6 +920,7 @@ __global__ __launch_bounds__(BLOCK) void traverse_cluster_kernel(TraverseParams 
 #ifdef RT_DBG_NO_A
     if (false)
 #endif
+    if (p.sweeps & 1)
     for (int tile_base = g_begin; tile_base < g_end; tile_base += GROUP_TILE) {
         __syncthreads();
         const int tile_n = min(GROUP_TILE, g_end - tile_base);
@@ -979,6 +988,7 @@ __global__ __launch_bounds__(BLOCK) void traverse_cluster_kernel(TraverseParams 
 #ifdef RT_DBG_NO_B
     if (false)
 #endif
+    if (p.sweeps & 2)
     for (int tile_base = c_begin; tile_base < c_end; tile_base += GROUP_TILE) {
         __syncthreads();
         const int tile_n = min(GROUP_TILE, c_end - tile_base);
@@ -1035,11 +1045,163 @@ __global__ __launch_bounds__(BLOCK) void traverse_cluster_kernel(TraverseParams 
         add_counter(p.counters, C_CH_CAND, n_cand);
         add_counter(p.counters, C_CH_SLOW, n_slow);
     }
-    if (tid == 0 && blockIdx.y == 0) {
+    if (tid == 0 && blockIdx.y == 0 && (p.sweeps & 2)) {
         const int mine = min(NR, n - s0);
         add_counter(p.counters, C_CH_PAIRS, (unsigned long long)mine * (unsigned long long)p.num_tris);
     }
     (void)any_wild;
+}
+
+// ---------------------------------------------------------------------------
+// Sweep A of the clustered traversal as a streaming kernel, for rays sorted by direction: the rays
+// of a wavefront then point the same way (up to sign), so a group of triangles with similar
+// normals holds either none of them -- the group is skipped -- or most of them, and its 64 member
+// records are walked with one lane per ray, read from LDS with wave-uniform addresses.  A ray
+// inside a member's band and slab goes through the general edge filter on the spot (the member's
+// edge record is read once for the wavefront); survivors are queued for the reference arithmetic.
+// Same pairs reach the reference arithmetic as in sweep A of traverse_cluster_kernel.
+// grid = (ray blocks, sub-ranges of the groups).
+// ---------------------------------------------------------------------------
+constexpr int BAND_TILE_GROUPS = 8; // groups per LDS tile: 512 member records of 32 bytes (16 KiB)
+
+template <int K>
+__global__ __launch_bounds__(BLOCK) void traverse_band_kernel(TraverseParams p)
+{
+    __shared__ float4 mem4[BAND_TILE_GROUPS * NGROUP * 2];
+    __shared__ float4 grp4[BAND_TILE_GROUPS];
+    __shared__ unsigned int queue_all[(BLOCK / 64) * qcap(K)];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = p.count ? *p.count : p.n;
+    const int s0 = blockIdx.x * (BLOCK * K);
+    if (s0 >= n) return;
+    int g_per_y = (p.num_ngroups + (int)gridDim.y - 1) / (int)gridDim.y;
+    g_per_y = (g_per_y + BAND_TILE_GROUPS - 1) / BAND_TILE_GROUPS * BAND_TILE_GROUPS;
+    const int g_begin = blockIdx.y * g_per_y, g_end = min(g_begin + g_per_y, p.num_ngroups);
+    if (g_begin >= g_end) return;
+
+    int slot[K];
+    float ox[K], oy[K], oz[K], bx[K], by[K], bz[K], hx[K], hy[K], hz[K];
+    bool valid[K], wild[K];
+    const float qn = __int_as_float(0x7fc00000);
+    bool any_wild = false;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int s = s0 + (wave * K + k) * 64 + lane;
+        valid[k] = s < n;
+        slot[k] = valid[k] ? (p.alist ? p.alist[s] : s) : 0;
+        ox[k] = oy[k] = oz[k] = bx[k] = by[k] = bz[k] = hx[k] = hy[k] = hz[k] = qn;
+        float g = qn;
+        if (valid[k]) {
+            ox[k] = p.job.ox[slot[k]]; oy[k] = p.job.oy[slot[k]]; oz[k] = p.job.oz[slot[k]];
+            bx[k] = p.job.bx[slot[k]]; by[k] = p.job.by[slot[k]]; bz[k] = p.job.bz[slot[k]];
+            g = p.job.g[slot[k]];
+            const float gg = fabsf(g);
+            hx[k] = p.job.dx[slot[k]] * gg; hy[k] = p.job.dy[slot[k]] * gg; hz[k] = p.job.dz[slot[k]] * gg;
+        }
+        wild[k] = valid[k] && !(g > 0.0f); // outside the records' range: in every band and slab
+        any_wild = any_wild || wild[k];
+    }
+    const bool wave_wild = any64(any_wild);
+
+    unsigned int *queue = queue_all + wave * qcap(K);
+    int qcount = 0; // wave-uniform
+    unsigned long long n_cand = 0, n_slow = 0;
+
+    // the reference arithmetic for queued (triangle, ray) pairs, one per lane
+    auto drain = [&](bool all) {
+        while (qcount >= 64 || (all && qcount > 0)) {
+            const int take = qcount >= 64 ? 64 : qcount;
+            qcount -= take;
+            if (lane < take) {
+                const unsigned int e = queue[qcount + lane];
+                const int tri = (int)(e >> 11);
+                const int s = s0 + (int)(e & 2047u);
+                const int sl = p.alist ? p.alist[s] : s;
+                const v3 o = rtx::V(p.job.ox[sl], p.job.oy[sl], p.job.oz[sl]);
+                const v3 d = rtx::V(p.job.dx[sl], p.job.dy[sl], p.job.dz[sl]);
+                const v3 X = vpos(p.verts, 3 * tri), Y = vpos(p.verts, 3 * tri + 1), Z = vpos(p.verts, 3 * tri + 2);
+                float t;
+                if (rtx::ray_vs_triangle(o, d, X, Y, Z, t) && t > 0.0f) {
+                    const unsigned long long key =
+                        ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)(unsigned int)tri;
+                    atomicMin(&p.best[sl], key);
+                }
+            }
+        }
+    };
+
+    for (int tile_base = g_begin; tile_base < g_end; tile_base += BAND_TILE_GROUPS) {
+        __syncthreads();
+        const int tile_g = min(BAND_TILE_GROUPS, g_end - tile_base);
+        const float4 *src = p.nrecs + (size_t)tile_base * NGROUP * 2;
+#pragma unroll
+        for (int i = 0; i < (BAND_TILE_GROUPS * NGROUP * 2) / BLOCK; i++) {
+            const int e = i * BLOCK + tid;
+            if (e < tile_g * NGROUP * 2) mem4[e] = src[e];
+        }
+        if (tid < tile_g) grp4[tid] = p.ngroups[tile_base + tid];
+        __syncthreads();
+        for (int gi = 0; gi < tile_g; gi++) {
+            const float4 gc = grp4[gi];
+            float G = fabsf(fmaf(gc.z, bz[0], fmaf(gc.y, by[0], gc.x * bx[0])));
+#pragma unroll
+            for (int k = 1; k < K; k++) G = fminf(G, fabsf(fmaf(gc.z, bz[k], fmaf(gc.y, by[k], gc.x * bx[k]))));
+            if (!(any64(G < gc.w) || wave_wild)) continue; // no ray of the wavefront in the group's band
+            const float4 *mrec = mem4 + gi * NGROUP * 2;
+            for (int j = 0; j < NGROUP; j += 2) {
+                const float4 a1 = mrec[2 * j], a2 = mrec[2 * j + 1], b1 = mrec[2 * j + 2], b2 = mrec[2 * j + 3];
+                float ta[K], tb[K];
+#pragma unroll
+                for (int k = 0; k < K; k++) {
+                    const float t0 = fmaf(a1.z, bz[k], fmaf(a1.y, by[k], a1.x * bx[k]));
+                    const float h0 = fmaf(a2.z, oz[k], fmaf(a2.y, oy[k], fmaf(a2.x, ox[k], -a1.w)));
+                    ta[k] = fmaxf(fabsf(t0), fabsf(h0));
+                    const float t1 = fmaf(b1.z, bz[k], fmaf(b1.y, by[k], b1.x * bx[k]));
+                    const float h1 = fmaf(b2.z, oz[k], fmaf(b2.y, oy[k], fmaf(b2.x, ox[k], -b1.w)));
+                    tb[k] = fmaxf(fabsf(t1), fabsf(h1));
+                }
+                float Ga = ta[0], Gb = tb[0];
+#pragma unroll
+                for (int k = 1; k < K; k++) { Ga = fminf(Ga, ta[k]); Gb = fminf(Gb, tb[k]); }
+                if (!(any64(Ga < 1.0f || Gb < 1.0f) || wave_wild)) continue;
+                n_slow++;
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const float4 m1 = u == 0 ? a1 : b1, m2 = u == 0 ? a2 : b2;
+                    const int tri = __float_as_int(m2.w);
+                    if (tri < 0 || m1.w == 2.0f) continue; // padding / never accepted (wave-uniform)
+                    const float Gu = u == 0 ? Ga : Gb;
+                    if (!(any64(Gu < 1.0f) || wave_wild)) continue;
+                    const float4 *er4 = reinterpret_cast<const float4 *>(p.recs + tri);
+                    const float4 e0 = er4[0], e1 = er4[1], e2 = er4[2];
+                    const float er[12] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w, e2.x, e2.y, e2.z, e2.w};
+#pragma unroll
+                    for (int k = 0; k < K; k++) {
+                        const float t = u == 0 ? ta[k] : tb[k];
+                        bool in = ((t < 1.0f) || wild[k]) && valid[k];
+                        if (any64(in))
+                            in = in && rtf::filter_general(er, ox[k], oy[k], oz[k], hx[k], hy[k], hz[k]) >= -1.0f;
+                        const unsigned long long m = __builtin_amdgcn_ballot_w64(in);
+                        if (m) {
+                            n_cand += __popcll(m);
+                            if (in)
+                                queue[qcount + lanes_below(m)] =
+                                    ((unsigned int)tri << 11) | (unsigned int)((wave * K + k) * 64 + lane);
+                            qcount += __popcll(m);
+                        }
+                    }
+                    if (qcount >= qcap(K) - 64 * K) drain(false);
+                }
+            }
+        }
+    }
+    drain(true);
+
+    if (lane == 0) {
+        add_counter(p.counters, C_CH_CAND, n_cand);
+        add_counter(p.counters, C_CH_SLOW, n_slow);
+    }
 }
 
 // ---------------------------------------------------------------------------
