@@ -424,7 +424,8 @@ RT_HD double scene_extent(const float O[3], const float C[3], float R)
 //   (A) |a^| >= K E.  Then u^ = Nu^/a^ (1 + 2 eps) differs from the true u = Nu/a by less than
 //       2/(K-1), likewise v; the reference accepts only 0 <= u^, 0 <= v^, u^ + v^ <= 1, so the point
 //       where the ray's LINE meets the triangle's plane lies within rho = 2/(K-1) (|e1| + |e2|) of
-//       the triangle: the line passes within rho of it.
+//       the triangle: the line passes within rho of it.  The same bounds applied to t = Nt/a show
+//       that a computed t > 0 has a true t >= -rho/|d|: the hit point is at most rho behind the origin.
 //   (B) |a^| < K E.  Then |a| < (K+1) E, i.e. the direction is nearly parallel to the plane:
 //       |d.n| / |d| < theta = (K+1) eps max(16 S / min(|e1|,|e2|), 14) / sin(angle(e1, e2)).
 //       In case (B) the reference accepts only if also |Nu^| <= |a^| and |Nv^| <= |a^| (u^, v^ <= 1),
@@ -509,7 +510,7 @@ RT_HD bool band_test(const float *rec, float bx, float by, float bz)
     return fabsf(t) < rec[3];
 }
 
-// Does the line through (ox,oy,oz) along the float-normalised direction (bx,by,bz) pass within
+// Does the half-line from (ox,oy,oz) along the float-normalised direction (bx,by,bz) pass within
 // the cluster's sphere?  rec = (centre, R^2 rounded up).  The 2^-20 |L|^2 slack covers the
 // cancellation in |L|^2 - (L.b)^2 and |b| != 1.
 RT_HD bool cluster_test(const float *rec, float ox, float oy, float oz, float bx, float by, float bz)
@@ -518,6 +519,9 @@ RT_HD bool cluster_test(const float *rec, float ox, float oy, float oz, float bx
     const float ll = fmaf(lz, lz, fmaf(ly, ly, lx * lx));
     const float b = fmaf(lz, bz, fmaf(ly, by, lx * bx));
     const float q = fmaf(-b, b, ll);
+    // behind the origin by more than twice the radius: the reference keeps t > 0 only, and a computed
+    // t > 0 with a well-conditioned determinant puts the true hit point at most rho (< R) behind it
+    if (b < 0.0f && b * b > 4.0f * rec[3]) return false;
     return fmaf(ll, -9.5367431640625e-07f, q) <= rec[3];
 }
 

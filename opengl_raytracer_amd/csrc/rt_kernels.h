@@ -1019,8 +1019,10 @@ __global__ __launch_bounds__(BLOCK) void traverse_cluster_kernel(TraverseParams 
             for (int k = 0; k < K; k++) {
                 unsigned long long mk = m[k];
                 const int rbase = (wave * K + k) * 64;
-                while (mk) {
-                    // the lower half of the wavefront takes the lowest set bit, the upper half the next
+                if (!mk) continue;
+                // the lower half of the wavefront takes the lowest set bit, the upper half the next;
+                // the records of the following pair of rays are fetched while this pair is tested
+                auto take2 = [&](int &src) {
                     const int s0b = __builtin_ctzll(mk);
                     mk &= mk - 1;
                     int s1b = -1;
@@ -1028,14 +1030,27 @@ __global__ __launch_bounds__(BLOCK) void traverse_cluster_kernel(TraverseParams 
                         s1b = __builtin_ctzll(mk);
                         mk &= mk - 1;
                     }
-                    const int src = (lane < 32) ? s0b : s1b;
+                    src = (lane < 32) ? s0b : s1b;
+                };
+                int src;
+                take2(src);
+                float4 ro = ray_o[rbase + (src < 0 ? 0 : src)], rh = ray_h[rbase + (src < 0 ? 0 : src)];
+                for (;;) {
+                    const bool more = mk != 0ull;
+                    int nsrc = -1;
+                    float4 no = ro, nh = rh;
+                    if (more) {
+                        take2(nsrc);
+                        no = ray_o[rbase + (nsrc < 0 ? 0 : nsrc)];
+                        nh = ray_h[rbase + (nsrc < 0 ? 0 : nsrc)];
+                    }
                     bool pass = false;
-                    const int r = rbase + (src < 0 ? 0 : src);
-                    const float4 ro = ray_o[r], rh = ray_h[r];
                     if (src >= 0 && tri >= 0)
                         pass = rtf::filter_general(rec, ro.x, ro.y, ro.z, rh.x, rh.y, rh.z) >= -1.0f;
                     n_cand += __popcll(__builtin_amdgcn_ballot_w64(pass));
-                    if (pass) confirm(r, tri);
+                    if (pass) confirm(rbase + src, tri);
+                    if (!more) break;
+                    src = nsrc; ro = no; rh = nh;
                 }
             }
         }
