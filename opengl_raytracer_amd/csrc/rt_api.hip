@@ -105,6 +105,8 @@ struct rt_ctx {
     hipStream_t stream = nullptr;
 
     int trace_mode = RT_TRACE_CLUSTERED;
+    // launches with at least this many rays sort them (RT_SORT_MIN_RAYS overrides: tests use a small value)
+    int sort_min_rays = 131072;
 
     float acc_ms[3] = {0, 0, 0};
     std::vector<EventPair> ev_pool;
@@ -235,6 +237,10 @@ extern "C" int rt_create(rt_ctx **out, int hip_device, int width, int height)
     CRCHK(hipMalloc(&c->list, c->cap * sizeof(int)));
     CRCHK(hipMalloc(&c->alist[0], c->cap * sizeof(int)));
     CRCHK(hipMalloc(&c->alist[1], c->cap * sizeof(int)));
+    if (const char *e = getenv("RT_SORT_MIN_RAYS")) {
+        const int v = atoi(e);
+        if (v > 0) c->sort_min_rays = v;
+    }
     CRCHK(hipMalloc(&c->sort_keys, c->cap * sizeof(unsigned int)));
     CRCHK(hipMalloc(&c->sort_keys_out, c->cap * sizeof(unsigned int)));
     CRCHK(hipMalloc(&c->sort_iota, c->cap * sizeof(int)));
@@ -845,7 +851,7 @@ extern "C" int rt_intersect(rt_ctx *c)
         }
         if (n_upper > 0) {
             const bool clustered = !shared && c->trace_mode == RT_TRACE_CLUSTERED;
-            const bool sorted = clustered && n_upper >= 131072 && c->num_ngroups >= 64;
+            const bool sorted = clustered && n_upper >= c->sort_min_rays && c->num_ngroups >= 64;
             hipLaunchKernelGGL(intersect_setup_kernel, dim3(cdiv(n_upper, BLOCK)), dim3(BLOCK), 0, c->stream, c->rays,
                                list, count, n_upper, c->job, c->scratch.best, shared ? 1 : (clustered ? 2 : 0),
                                shared_origin(c, c->cam.pos, 1.0f), sorted ? c->sort_keys : (unsigned int *)nullptr);
@@ -929,7 +935,7 @@ extern "C" int rt_color(rt_ctx *c)
                 for (int a = 0; a < c->num_lights; a++) {
                     // in the clustered mode the shadow rays are visited in the order of the direction in
                     // which they leave the light (any order gives the same result)
-                    const bool sorted = c->trace_mode == RT_TRACE_CLUSTERED && n0 >= 131072 && c->num_slots >= 8192;
+                    const bool sorted = c->trace_mode == RT_TRACE_CLUSTERED && n0 >= c->sort_min_rays && c->num_slots >= 8192;
                     hipLaunchKernelGGL(shadow_setup_kernel, g0, dim3(BLOCK), 0, c->stream, cnt0, c->scratch, c->job,
                                        c->lights[a].pos[0], c->lights[a].pos[1], c->lights[a].pos[2],
                                        shared_origin(c, c->lights[a].pos, -1.0f), c->counters_d,

@@ -289,6 +289,34 @@ def test_full_size_filtered_equals_exact_and_is_idempotent(rt):
         assert (pix_a.reshape(-1, 4) != [26, 26, 26, 255]).any(axis=1).mean() > 0.05
 
 
+def test_sorted_ray_paths_against_oracle(rt, oracle_mod, monkeypatch):
+    """The clustered mode's sorted-ray kernels (bounce rays sorted by direction for the band sweep,
+    shadow rays sorted by the direction in which they leave the light) normally start at 131072 rays
+    per launch; RT_SORT_MIN_RAYS lowers that so that a frame the oracle can do exercises them:
+    512 x 288 rays, 8 400 triangles, three passes."""
+    from opengl_raytracer_amd import scenes
+    monkeypatch.setenv("RT_SORT_MIN_RAYS", "4096")
+    w, h = 512, 288
+    mesh = scenes.concat_meshes(scenes.triangle_soup(8000, seed=99, extent=1.0, size=0.08),
+                                scenes.quad_grid(10, 20, origin=(-1.5, -1.2, 1.2), du=(3.0, 0.0, 0.0), dv=(0.0, 2.4, 0.3)))
+    cam = scenes.look_at_camera((0.2, 0.1, -2.6), (0.0, 0.0, 0.0))
+    g, c = make_pair(rt, oracle_mod, w, h, threads=16)
+    with g:
+        for o in (g, c):
+            o.set_mesh(mesh)
+            o.set_texture(scenes.noise_texture(128, 128))
+            o.set_lights(scenes.default_lights(), 1)
+            o.set_camera(*cam)
+        g.counters()
+        g.render(3); c.render(3)
+        assert_same("sorted paths", g, c)
+        assert_same_pixels("sorted paths", g, c)
+        log = g.kernel_log()
+        # the bounce passes ran as two kernels (band sweep with 4 rays per lane, sphere sweep with 2)
+        forms = [(int(r["form"]), int(r["rays_per_lane"])) for r in log if int(r["stage"]) == 1]
+        assert (2, 4) in forms and (2, 2) in forms, forms
+
+
 # -- error behaviour -----------------------------------------------------------------------
 def test_error_codes(rt):
     with rt.RayTracer(16, 16) as g:
