@@ -420,14 +420,16 @@ RT_HD double scene_extent(const float O[3], const float C[3], float R)
 // s = o - X, a = e1.(d x e2), Nu = s.(d x e2), Nv = d.(s x e1), and a^, Nu^, Nv^ for what it
 // computes.  First-order rounding analysis of its operation sequence gives
 //     |a^ - a| <= 7 eps |e1||e2||d|,  |Nu^ - Nu| <= 8 eps |s||d||e2|,  |Nv^ - Nv| <= 8 eps |s||d||e1|.
-// Let E = eps |d| max(16 S |e1|, 16 S |e2|, 14 |e1||e2|) with S >= |s| (twice those bounds).
+// (Sampled over 2e7 random and near-coplanar pairs the three errors stay below 4.1 eps times those
+// magnitudes.)  Let E = eps |d| max(9 S |e1|, 9 S |e2|, 8 |e1||e2|) with S >= |s|: above those bounds
+// with room for the second-order terms.
 //   (A) |a^| >= K E.  Then u^ = Nu^/a^ (1 + 2 eps) differs from the true u = Nu/a by less than
 //       2/(K-1), likewise v; the reference accepts only 0 <= u^, 0 <= v^, u^ + v^ <= 1, so the point
 //       where the ray's LINE meets the triangle's plane lies within rho = 2/(K-1) (|e1| + |e2|) of
 //       the triangle: the line passes within rho of it.  The same bounds applied to t = Nt/a show
 //       that a computed t > 0 has a true t >= -rho/|d|: the hit point is at most rho behind the origin.
 //   (B) |a^| < K E.  Then |a| < (K+1) E, i.e. the direction is nearly parallel to the plane:
-//       |d.n| / |d| < theta = (K+1) eps max(16 S / min(|e1|,|e2|), 14) / sin(angle(e1, e2)).
+//       |d.n| / |d| < theta = (K+1) eps max(9 S / min(|e1|,|e2|), 8) / sin(angle(e1, e2)).
 //       In case (B) the reference accepts only if also |Nu^| <= |a^| and |Nv^| <= |a^| (u^, v^ <= 1),
 //       so Nu and Nv are below (K+1) E too; with m = s x d, Nu = m.e2, Nv = -m.e1, and
 //           s.n = (-(s.d) a + Nv (d.e2) + Nu (d.e1)) / |d|^2,    n = e1 x e2,
@@ -475,8 +477,8 @@ RT_HD double make_band_rec(const float X[3], const float Y[3], const float Z[3],
     const double emin = l1 < l2 ? l1 : l2, elong = l1 < l2 ? l2 : l1;
     if (!(emin > 1e-12) || !(elong < 1e12) || !(nl > 0.0) || !(S > 0.0) || !(S < 1e12)) return -1.0;
     const double sinphi = nl / (l1 * l2);
-    double w = 16.0 * S / emin;
-    if (w < 14.0) w = 14.0;
+    double w = 9.0 * S / emin;
+    if (w < 8.0) w = 8.0;
     const double theta = (BAND_K + 1.0) * 5.9604644775390625e-08 * w / sinphi + 9.5367431640625e-07; // eps = 2^-24; 2^-20
     if (!(theta < 0.5)) return -1.0;
     out->v[0] = (float)(n[0] / nl);
