@@ -78,8 +78,10 @@ inline void build_normal_groups(ClusterSet &cs);
 
 inline void build(const rt_vertex *v, int num_tris, const float center[3], float radius, ClusterSet &out)
 {
-    out.S = 3.0 * (double)radius * 1.001;          // origin within 2R of the centre, vertex within R
-    out.origin_limit = 2.0 * (double)radius;
+    // rays that start inside the bounding sphere (every bounce ray does: it starts on a surface) plus
+    // a little: |o - centre| <= 1.25 R, vertex within R
+    out.origin_limit = 1.25 * (double)radius;
+    out.S = 2.25 * (double)radius * 1.001;
     out.bands.assign((size_t)num_tris, rtf::BandRec{{0.0f, 0.0f, 0.0f, -1.0f}});
     out.slabs.assign((size_t)num_tris, rtf::SlabRec{{0.0f, INFINITY}});
     const double abs_extent = std::sqrt((double)center[0] * center[0] + (double)center[1] * center[1] +

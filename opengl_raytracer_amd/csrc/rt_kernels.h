@@ -296,7 +296,7 @@ __device__ __forceinline__ void prepare_shared(const Job &job, int slot, v3 o, v
 
 // fills job.b* and job.g for an arbitrary ray (clustered traversal): unit direction, and the
 // general filter's dir_scale, negated when the origin lies outside the range the band records
-// were built for (|o - centre| <= 2 radius)
+// were built for (|o - centre| <= 1.25 radius)
 __device__ __forceinline__ void prepare_general(const Job &job, int slot, v3 o, v3 d, const float *center, float radius)
 {
     const v3 oc = rtx::V(o.x - center[0], o.y - center[1], o.z - center[2]);
@@ -304,7 +304,7 @@ __device__ __forceinline__ void prepare_general(const Job &job, int slot, v3 o, 
     const float g = rtf::dir_scale(dist + 3.0f * radius, d.x, d.y, d.z);
     const float inv = 1.0f / sqrtf(rtx::dot(d, d));
     job.bx[slot] = d.x * inv; job.by[slot] = d.y * inv; job.bz[slot] = d.z * inv;
-    job.g[slot] = (dist <= 2.0f * radius) ? g : -g;
+    job.g[slot] = (dist <= 1.25f * radius) ? g : -g;
 }
 
 struct SharedOrigin { // the shared origin of a launch and the validity range of its cones

@@ -170,7 +170,7 @@ extern "C" void fm_check_clustered(int n_tris, const float *verts, int n_rays, c
         const float g0 = rtf::dir_scale(dist + 3.0f * radius, d[0], d[1], d[2]);
         const float inv = 1.0f / sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
         const float bx = d[0] * inv, by = d[1] * inv, bz = d[2] * inv;
-        const float g = (dist <= 2.0f * radius) ? g0 : -g0;
+        const float g = (dist <= 1.25f * radius) ? g0 : -g0;
         const bool wild = !(g > 0.0f);
         const float gg = fabsf(g);
         wildn += wild;
