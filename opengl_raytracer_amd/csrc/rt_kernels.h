@@ -541,6 +541,10 @@ __global__ __launch_bounds__(BLOCK) void traverse_kernel(TraverseParams p)
 
     unsigned long long n_cand = 0, n_slow = 0;
     int tris_done = 0;
+#ifdef RT_DBG_TIMING
+    unsigned long long tm_tile = 0, tm_drain = 0, tm_slow = 0;
+    const unsigned long long tm_start = __builtin_amdgcn_s_memtime();
+#endif
 
     // second level (FORM 1) / candidate handling for one triangle; `pass` says which of the
     // lane's rays go to the reference arithmetic
@@ -570,7 +574,7 @@ __global__ __launch_bounds__(BLOCK) void traverse_kernel(TraverseParams p)
     const int lane = tid & 63;
 
     // Level 2 and the reference arithmetic for queued pairs, one pair per lane.
-    auto drain = [&](bool all) {
+    auto drain_body = [&](bool all) {
 #ifdef RT_DBG_NO_DRAIN
         qcount = 0;
         return;
@@ -622,7 +626,20 @@ __global__ __launch_bounds__(BLOCK) void traverse_kernel(TraverseParams p)
         }
     };
 
+    auto drain = [&](bool all) {
+#ifdef RT_DBG_TIMING
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        drain_body(all);
+        tm_drain += __builtin_amdgcn_s_memtime() - t0;
+#else
+        drain_body(all);
+#endif
+    };
+
     for (int tile_base = t_begin; tile_base < t_end; tile_base += TSZ) {
+#ifdef RT_DBG_TIMING
+        const unsigned long long tt0 = __builtin_amdgcn_s_memtime();
+#endif
         if (ANYHIT) {
             bool all_occ = true;
 #pragma unroll
@@ -650,6 +667,9 @@ __global__ __launch_bounds__(BLOCK) void traverse_kernel(TraverseParams p)
         }
         __syncthreads();
         tris_done += tile_n;
+#ifdef RT_DBG_TIMING
+        tm_tile += __builtin_amdgcn_s_memtime() - tt0;
+#endif
 
         if (EXACT) {
             for (int j = 0; j < tile_n; j++) {
@@ -717,6 +737,9 @@ __global__ __launch_bounds__(BLOCK) void traverse_kernel(TraverseParams p)
 #ifndef RT_DBG_NO_SLOW
                 if (any64(h0 || h1 || h2 || h3) || wave_wild) {
                     n_slow++;
+#ifdef RT_DBG_TIMING
+                    const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
                         const float w = (u == 0) ? c0.w : (u == 1) ? c1.w : (u == 2) ? c2.w : c3.w;
@@ -748,6 +771,9 @@ __global__ __launch_bounds__(BLOCK) void traverse_kernel(TraverseParams p)
                         }
                         if (qcount >= qcap(K) - 64 * K) drain(false);
                     }
+#ifdef RT_DBG_TIMING
+                    tm_slow += __builtin_amdgcn_s_memtime() - ts0;
+#endif
                 }
 #else
                 if (any64(h0 || h1 || h2 || h3) || wave_wild) n_slow++;
@@ -766,10 +792,20 @@ __global__ __launch_bounds__(BLOCK) void traverse_kernel(TraverseParams p)
     }
     if (FORM == 1 && !EXACT) drain(true);
 
+#ifdef RT_DBG_TIMING
+    if ((tid & 63) == 0 && FORM == 1) {
+        // per-wavefront cycles: [4] tile loads + barriers, [5] queue handling, [6] slow path incl. [5], [7] total
+        add_counter(p.counters, 4, tm_tile);
+        add_counter(p.counters, 5, tm_drain);
+        add_counter(p.counters, 6, tm_slow);
+        add_counter(p.counters, 7, __builtin_amdgcn_s_memtime() - tm_start);
+    }
+#else
     if ((tid & 63) == 0) {
         add_counter(p.counters, ANYHIT ? C_SH_CAND : C_CH_CAND, n_cand);
         add_counter(p.counters, ANYHIT ? C_SH_SLOW : C_CH_SLOW, n_slow);
     }
+#endif
     if (tid == 0) {
         const int mine = min(BLOCK * K, n - s0);
         add_counter(p.counters, ANYHIT ? C_SH_PAIRS : C_CH_PAIRS,
