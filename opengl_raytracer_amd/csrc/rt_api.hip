@@ -640,7 +640,11 @@ static int pick_rays_per_lane(int n)
 // workgroups (8 per CU): short launches then fill the chip and end together.
 static int pick_tiles_per_y(int ray_blocks, int tiles)
 {
-    int want_y = (2048 + ray_blocks - 1) / ray_blocks;
+    static const int target = [] {
+        const char *e = getenv("RT_TARGET_BLOCKS");
+        return (e && atoi(e) > 0) ? atoi(e) : 8192;
+    }();
+    int want_y = (target + ray_blocks - 1) / ray_blocks;
     if (want_y < 1) want_y = 1;
     if (want_y > tiles) want_y = tiles;
     return (tiles + want_y - 1) / want_y;
@@ -726,7 +730,11 @@ static int launch_traverse_clustered(rt_ctx *c, TraverseParams p, int n_upper, b
             a.n = n_upper;
             const int k = 4;
             const int ray_blocks = cdiv(n_upper, BLOCK * k);
-            int want_y = (2048 + ray_blocks - 1) / ray_blocks;
+            static const int band_target = [] {
+                const char *e = getenv("RT_TARGET_BLOCKS_BAND");
+                return (e && atoi(e) > 0) ? atoi(e) : 8192;
+            }();
+            int want_y = (band_target + ray_blocks - 1) / ray_blocks;
             const int max_y = cdiv(c->num_ngroups, BAND_TILE_GROUPS);
             if (want_y > max_y) want_y = max_y;
             if (want_y < 1) want_y = 1;

@@ -794,9 +794,10 @@ __global__ __launch_bounds__(BLOCK) void traverse_kernel(TraverseParams p)
 
 #ifdef RT_DBG_TIMING
     if ((tid & 63) == 0 && FORM == 1) {
-        // per-wavefront cycles: [4] tile loads + barriers, [5] queue handling, [6] slow path incl. [5], [7] total
+        // per-wavefront cycles: [4] tile loads + barriers, [5] longest wavefront, [6] slow path, [7] total
         add_counter(p.counters, 4, tm_tile);
-        add_counter(p.counters, 5, tm_drain);
+        (void)tm_drain;
+        atomicMax(p.counters + 5, __builtin_amdgcn_s_memtime() - tm_start); // longest wavefront
         add_counter(p.counters, 6, tm_slow);
         add_counter(p.counters, 7, __builtin_amdgcn_s_memtime() - tm_start);
     }

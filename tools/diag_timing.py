@@ -8,6 +8,6 @@ g.render(2); g.sync(); g.counters()
 g.raygen()
 for p in range(3):
     g.intersect(); c = g.counters(); k = list(c.values())
-    if p == 0: print("pass0 intersect(FORM1 closest): waves?  tile %.3g drain %.3g slow %.3g total %.3g cycles" % (k[4], k[5], k[6], k[7]))
+    if p == 0: print("pass0 intersect(FORM1 closest): waves?  tile %.3g longest wave %.3g slow %.3g total %.3g cycles" % (k[4], k[5], k[6], k[7]))
     g.color(); c = g.counters(); k = list(c.values())
-    print("pass%d color (FORM1 anyhit): tile %.3g drain %.3g slow(incl drain) %.3g total %.3g cycles; shadow rays %d" % (p, k[4], k[5], k[6], k[7], k[1]))
+    print("pass%d color (FORM1 anyhit): tile %.3g longest wave %.3g slow(incl drain) %.3g total %.3g cycles; shadow rays %d" % (p, k[4], k[5], k[6], k[7], k[1]))
