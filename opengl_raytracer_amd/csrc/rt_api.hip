@@ -631,6 +631,8 @@ extern "C" int rt_raygen(rt_ctx *c)
 // fewer rays give small launches enough lanes to spread over 256 CUs.
 static int pick_rays_per_lane(int n)
 {
+    static const int forced = getenv("RT_FORCE_K") ? atoi(getenv("RT_FORCE_K")) : 0;
+    if (forced == 1 || forced == 2 || forced == 4) return forced;
     if (n >= 65536) return 4;
     if (n >= 16384) return 2;
     return 1;
@@ -904,7 +906,11 @@ extern "C" int rt_intersect(rt_ctx *c)
 // triangles per shadow chunk: rays found occluded in one chunk are dropped before the next
 static int shadow_chunk_tris(int num_tris)
 {
-    static const int parts = getenv("RT_SHADOW_CHUNKS") ? atoi(getenv("RT_SHADOW_CHUNKS")) : 2;
+    static const int parts = [] {
+        const char *e = getenv("RT_SHADOW_CHUNKS");
+        const int v = e ? atoi(e) : 2;
+        return (v >= 1 && v <= 64) ? v : 2;
+    }();
     int chunk = (num_tris + parts - 1) / parts;
     if (chunk < 4096) chunk = 4096;
     return (chunk + CONE_TILE - 1) / CONE_TILE * CONE_TILE;
