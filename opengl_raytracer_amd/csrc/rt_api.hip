@@ -751,8 +751,11 @@ static int launch_traverse_clustered(rt_ctx *c, TraverseParams p, int n_upper, b
     } else {
         p.sweeps = 3;
     }
-    // 48 bytes of LDS per staged ray: two rays per lane keep four workgroups on a CU
-    const int k = n_upper >= 16384 ? 2 : 1;
+    // 32 (sphere sweep only) or 48 bytes of LDS per staged ray; one ray per lane keeps seven
+    // workgroups on a CU, which hides the latency of the member loops better than two rays per
+    // lane save sphere-test overhead
+    static const int forced_k = getenv("RT_CLUSTER_K") ? atoi(getenv("RT_CLUSTER_K")) : 0;
+    const int k = forced_k == 2 ? 2 : 1;
     const int ray_blocks = cdiv(n_upper, BLOCK * k);
     p.tiles_per_y = pick_tiles_per_y(ray_blocks, tiles);
     p.tiles_per_y = (p.tiles_per_y + CONE_TILE / TILE - 1) / (CONE_TILE / TILE) * (CONE_TILE / TILE);
@@ -760,8 +763,13 @@ static int launch_traverse_clustered(rt_ctx *c, TraverseParams p, int n_upper, b
     if (int r = klog_begin(c, 1, 2, k, false, (unsigned long long)n_upper,
                            sorted ? 0ull : (unsigned long long)n_upper * (unsigned long long)(p.tri_end - p.tri_begin), &ks))
         return r;
-    if (k == 2) hipLaunchKernelGGL((traverse_cluster_kernel<2>), grid, dim3(BLOCK), 0, c->stream, p);
-    else hipLaunchKernelGGL((traverse_cluster_kernel<1>), grid, dim3(BLOCK), 0, c->stream, p);
+    if (p.sweeps == 2) {
+        if (k == 2) hipLaunchKernelGGL((traverse_cluster_kernel<2, 2>), grid, dim3(BLOCK), 0, c->stream, p);
+        else hipLaunchKernelGGL((traverse_cluster_kernel<1, 2>), grid, dim3(BLOCK), 0, c->stream, p);
+    } else {
+        if (k == 2) hipLaunchKernelGGL((traverse_cluster_kernel<2, 3>), grid, dim3(BLOCK), 0, c->stream, p);
+        else hipLaunchKernelGGL((traverse_cluster_kernel<1, 3>), grid, dim3(BLOCK), 0, c->stream, p);
+    }
     HIPCHK(c, hipGetLastError());
     return klog_end(c, ks);
 }

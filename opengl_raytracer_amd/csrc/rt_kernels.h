@@ -406,7 +406,7 @@ struct TraverseParams {
     int *occ;
     unsigned long long *counters;
     // clustered traversal of arbitrary rays (traverse_cluster_kernel) only
-    int sweeps;                 // traverse_cluster_kernel: bit 0 = sweep A (bands), bit 1 = sweep B (spheres)
+    int sweeps;                 // host side: which instantiation of traverse_cluster_kernel (bit 0 = sweep A, bit 1 = sweep B)
     const float4 *ngroups;      // one (axis, w) per group of triangles with similar normals
     const float4 *nrecs;        // the members, two float4 each: (n/theta, kappa/H), (n/H, triangle index);
                                 // inside the member's band and slab <=> max(|n1.b|, |n2.o - kappa'|) < 1
@@ -849,13 +849,13 @@ constexpr int CLUSTER = 32;
 constexpr int NGROUP = 64;
 constexpr int GROUP_TILE = 512; // group records per LDS tile (8 KiB)
 
-template <int K>
+template <int K, int SWEEPS>
 __global__ __launch_bounds__(BLOCK) void traverse_cluster_kernel(TraverseParams p)
 {
     constexpr int NR = BLOCK * K;
     __shared__ float4 tile[GROUP_TILE];
-    // the workgroup's rays: (unit direction, |g|), (origin, slot), (direction * |g|, -)
-    __shared__ float4 ray_b[NR], ray_o[NR], ray_h[NR];
+    // the workgroup's rays: (unit direction, |g|) for sweep A, (origin, slot), (direction * |g|, -)
+    __shared__ float4 ray_b[(SWEEPS & 1) ? NR : 1], ray_o[NR], ray_h[NR];
     __shared__ unsigned int queue_all[(BLOCK / 64) * qcap(1)];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -887,7 +887,7 @@ __global__ __launch_bounds__(BLOCK) void traverse_cluster_kernel(TraverseParams 
         // outside the range the band records were built for: every band holds this ray
         wild[k] = valid[k] && !(g > 0.0f);
         const float gg = fabsf(g);
-        ray_b[r] = make_float4(bx[k], by[k], bz[k], gg);
+        if (SWEEPS & 1) ray_b[r] = make_float4(bx[k], by[k], bz[k], gg);
         ray_o[r] = make_float4(ox[k], oy[k], oz[k], __int_as_float(sl));
         ray_h[r] = make_float4(dx * gg, dy * gg, dz * gg, 0.0f);
     }
@@ -951,13 +951,34 @@ __global__ __launch_bounds__(BLOCK) void traverse_cluster_kernel(TraverseParams 
         }
     };
 
+    // sweep B's queue: pairs that passed the edge filter, for the reference arithmetic with one pair per lane
+    auto drain_hits = [&](bool all) {
+        while (qcount >= 64 || (all && qcount > 0)) {
+            const int take = qcount >= 64 ? 64 : qcount;
+            qcount -= take;
+            if (lane < take) {
+                const unsigned int e = queue[qcount + lane];
+                confirm((int)(e & 2047u), (int)(e >> 11));
+            }
+        }
+    };
+    auto push_hits = [&](bool in, int tri, int r) {
+        const unsigned long long h = __builtin_amdgcn_ballot_w64(in);
+        if (h) {
+            n_cand += __popcll(h);
+            if (in) queue[qcount + lanes_below(h)] = ((unsigned int)tri << 11) | (unsigned int)r;
+            qcount += __popcll(h);
+            if (qcount >= qcap(1) - 64) drain_hits(false);
+        }
+    };
+
     __syncthreads(); // the staged rays
 
     // ---- sweep A: groups by normal direction
 #ifdef RT_DBG_NO_A
     if (false)
 #endif
-    if (p.sweeps & 1)
+    if (SWEEPS & 1)
     for (int tile_base = g_begin; tile_base < g_end; tile_base += GROUP_TILE) {
         __syncthreads();
         const int tile_n = min(GROUP_TILE, g_end - tile_base);
@@ -1025,7 +1046,7 @@ __global__ __launch_bounds__(BLOCK) void traverse_cluster_kernel(TraverseParams 
 #ifdef RT_DBG_NO_B
     if (false)
 #endif
-    if (p.sweeps & 2)
+    if (SWEEPS & 2)
     for (int tile_base = c_begin; tile_base < c_end; tile_base += GROUP_TILE) {
         __syncthreads();
         const int tile_n = min(GROUP_TILE, c_end - tile_base);
@@ -1084,20 +1105,20 @@ __global__ __launch_bounds__(BLOCK) void traverse_cluster_kernel(TraverseParams 
                     bool pass = false;
                     if (src >= 0 && tri >= 0)
                         pass = rtf::filter_general(rec, ro.x, ro.y, ro.z, rh.x, rh.y, rh.z) >= -1.0f;
-                    n_cand += __popcll(__builtin_amdgcn_ballot_w64(pass));
-                    if (pass) confirm(rbase + src, tri);
+                    push_hits(pass, tri, rbase + (src < 0 ? 0 : src));
                     if (!more) break;
                     src = nsrc; ro = no; rh = nh;
                 }
             }
         }
     }
+    drain_hits(true);
 
     if (lane == 0) {
         add_counter(p.counters, C_CH_CAND, n_cand);
         add_counter(p.counters, C_CH_SLOW, n_slow);
     }
-    if (tid == 0 && blockIdx.y == 0 && (p.sweeps & 2)) {
+    if (tid == 0 && blockIdx.y == 0 && (SWEEPS & 2)) {
         const int mine = min(NR, n - s0);
         add_counter(p.counters, C_CH_PAIRS, (unsigned long long)mine * (unsigned long long)p.num_tris);
     }

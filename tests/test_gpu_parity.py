@@ -312,9 +312,9 @@ def test_sorted_ray_paths_against_oracle(rt, oracle_mod, monkeypatch):
         assert_same("sorted paths", g, c)
         assert_same_pixels("sorted paths", g, c)
         log = g.kernel_log()
-        # the bounce passes ran as two kernels (band sweep with 4 rays per lane, sphere sweep with 2)
+        # the bounce passes ran as two kernels (band sweep with 4 rays per lane, sphere sweep with 1)
         forms = [(int(r["form"]), int(r["rays_per_lane"])) for r in log if int(r["stage"]) == 1]
-        assert (2, 4) in forms and (2, 2) in forms, forms
+        assert (2, 4) in forms and (2, 1) in forms, forms
 
 
 # -- error behaviour -----------------------------------------------------------------------
