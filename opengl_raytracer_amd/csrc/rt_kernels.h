@@ -466,8 +466,11 @@ __device__ __forceinline__ int lanes_below(unsigned long long mask)
                                           __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
 }
 
+// The shared-origin form is latency-bound in its run and queue handling: six wavefronts per SIMD
+// (80 VGPRs, a handful of spills) beat the four the register allocator would settle for.
 template <int K, int FORM, bool ANYHIT, bool EXACT>
-__global__ __launch_bounds__(BLOCK) void traverse_kernel(TraverseParams p)
+__global__ __attribute__((amdgpu_waves_per_eu((FORM == 1 && !EXACT) ? 6 : 1, (FORM == 1 && !EXACT) ? 6 : 8)))
+__launch_bounds__(BLOCK) void traverse_kernel(TraverseParams p)
 {
     // FORM 0: tiles of 256 edge records (12 KiB).  FORM 1: tiles of 1024 cone records (16 KiB);
     // the edge records are only touched by the rare second level and stay in global memory.
@@ -1138,7 +1141,7 @@ __global__ __launch_bounds__(BLOCK) void traverse_cluster_kernel(TraverseParams 
 constexpr int BAND_TILE_GROUPS = 8; // groups per LDS tile: 512 member records of 32 bytes (16 KiB)
 
 template <int K>
-__global__ __launch_bounds__(BLOCK) void traverse_band_kernel(TraverseParams p)
+__global__ __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(BLOCK) void traverse_band_kernel(TraverseParams p)
 {
     __shared__ float4 mem4[BAND_TILE_GROUPS * NGROUP * 2];
     __shared__ float4 grp4[BAND_TILE_GROUPS];
