@@ -107,6 +107,7 @@ struct rt_ctx {
     int trace_mode = RT_TRACE_CLUSTERED;
     // launches with at least this many rays sort them (RT_SORT_MIN_RAYS overrides: tests use a small value)
     int sort_min_rays = 131072;
+    int cluster_min_tris = 1024;     // smaller meshes: bounce rays take the per-pair filter (RT_CLUSTER_MIN_TRIS)
 
     float acc_ms[3] = {0, 0, 0};
     std::vector<EventPair> ev_pool;
@@ -240,6 +241,10 @@ extern "C" int rt_create(rt_ctx **out, int hip_device, int width, int height)
     if (const char *e = getenv("RT_SORT_MIN_RAYS")) {
         const int v = atoi(e);
         if (v > 0) c->sort_min_rays = v;
+    }
+    if (const char *e = getenv("RT_CLUSTER_MIN_TRIS")) {
+        const int v = atoi(e);
+        if (v >= 0) c->cluster_min_tris = v;
     }
     CRCHK(hipMalloc(&c->sort_keys, c->cap * sizeof(unsigned int)));
     CRCHK(hipMalloc(&c->sort_keys_out, c->cap * sizeof(unsigned int)));
@@ -868,7 +873,9 @@ extern "C" int rt_intersect(rt_ctx *c)
             count = c->count_d;
         }
         if (n_upper > 0) {
-            const bool clustered = !shared && c->trace_mode == RT_TRACE_CLUSTERED;
+            // a few hundred triangles are streamed through the per-pair filter faster than their groups
+            // are swept
+            const bool clustered = !shared && c->trace_mode == RT_TRACE_CLUSTERED && c->num_tris >= c->cluster_min_tris;
             const bool sorted = clustered && n_upper >= c->sort_min_rays && c->num_ngroups >= 64;
             hipLaunchKernelGGL(intersect_setup_kernel, dim3(cdiv(n_upper, BLOCK)), dim3(BLOCK), 0, c->stream, c->rays,
                                list, count, n_upper, c->job, c->scratch.best, shared ? 1 : (clustered ? 2 : 0),

@@ -60,6 +60,26 @@ def test_reference_scenes_against_oracle(rt, oracle_mod, host, name, w, h, passe
         assert (g.read_pixels()[..., :3] != grey).any(-1).mean() > 0.1  # the scene is in the frame
 
 
+def test_small_mesh_default_threshold(rt, oracle_mod, host, monkeypatch):
+    """Without RT_CLUSTER_MIN_TRIS (the other tests run with 0) the bounce rays of the 165-triangle
+    sword go through the per-pair filter (form 0 in the kernel log): same bits as the oracle."""
+    monkeypatch.delenv("RT_CLUSTER_MIN_TRIS", raising=False)
+    mesh, tex, cam = scene(host, "sword")
+    w, h = 160, 160
+    g, c = rt.RayTracer(w, h), oracle_mod.Oracle(w, h, threads=16)
+    with g:
+        for o in (g, c):
+            o.set_mesh(mesh); o.set_texture(tex); o.set_lights(host.default_lights(), 2); o.set_camera(*cam)
+        g.kernel_log()
+        g.render(2); c.render(2)
+        got, want = g.read_rays(), c.read_rays()
+        bad = rays_equal_bits(got, want)
+        assert not bad.any(), describe_mismatch(got, want, bad)
+        assert np.array_equal(g.read_pixels(), c.read_pixels())
+        forms = [int(r["form"]) for r in g.kernel_log() if int(r["stage"]) == 1]
+        assert forms == [1, 0], forms
+
+
 def test_frame_loop_program(rt, oracle_mod, host, tmp_path):
     """rt_raytracer (the reference's RunRaytracer over the C ABI): its frame file equals the frame
     the Python mirror and the oracle produce from the same inputs; its CSV has the reference's
