@@ -87,11 +87,16 @@ def setup_scene(obj, wl):
 
 def cpu_baseline(wl, seconds_hint=15.0):
     """The oracle (a port of the reference's shaders) on the host cores, on a bounded sample:
-    the same scene and camera at 1/20 of the width and height (1/400 of the rays)."""
+    the same scene and camera on a frame scaled down in width and height."""
     from oracle.rt_oracle import Oracle
     threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
     threads = max(1, min(threads, 64))
-    w, h = max(1, wl["width"] // 20), max(1, wl["height"] // 20)
+    # the frame is scaled so that the sample is about 1.7e10 (ray, triangle) tests: 1/20 of the width and
+    # height for the 64K-triangle 4K frame, the whole frame for scenes of a few hundred triangles
+    tris = max(1, int(wl["mesh"].shape[0] // 3))
+    per_frame = float(wl["width"]) * wl["height"] * tris * wl["passes"] * (1 + wl["lights"])
+    div = max(1, int(round((per_frame / 1.7e10) ** 0.5)))
+    w, h = max(1, wl["width"] // div), max(1, wl["height"] // div)
     o = Oracle(w, h, threads=threads)
     setup_scene(o, wl)
     rays = 0
@@ -110,7 +115,7 @@ def cpu_baseline(wl, seconds_hint=15.0):
             break
     dt = time.perf_counter() - t0
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": f"same scene, {n_views} view(s) at {w}x{h} (1/400 of the rays per view), "
+            "sample": f"same scene, {n_views} view(s) at {w}x{h} (1/{div * div} of the rays per view), "
                       f"{wl['passes']} passes, oracle with {threads} OpenMP threads, {dt:.1f} s"}
 
 
