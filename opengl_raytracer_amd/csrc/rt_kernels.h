@@ -1133,8 +1133,9 @@ __global__ __launch_bounds__(BLOCK) void traverse_cluster_kernel(TraverseParams 
 // of a wavefront then point the same way (up to sign), so a group of triangles with similar
 // normals holds either none of them -- the group is skipped -- or most of them, and its 64 member
 // records are walked with one lane per ray, read from LDS with wave-uniform addresses.  A ray
-// inside a member's band and slab goes through the general edge filter on the spot (the member's
-// edge record is read once for the wavefront); survivors are queued for the reference arithmetic.
+// inside a member's band and slab is queued; the queue is handled 64 pairs at a time, one per lane:
+// general edge filter, then the reference arithmetic (doing either on the spot stalls the whole
+// wavefront on a chain of dependent loads for the sake of a lane or two).
 // Same pairs reach the reference arithmetic as in sweep A of traverse_cluster_kernel.
 // grid = (ray blocks, sub-ranges of the groups).
 // ---------------------------------------------------------------------------
@@ -1157,7 +1158,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(BLOCK) v
     if (g_begin >= g_end) return;
 
     int slot[K];
-    float ox[K], oy[K], oz[K], bx[K], by[K], bz[K], hx[K], hy[K], hz[K];
+    float ox[K], oy[K], oz[K], bx[K], by[K], bz[K];
     bool valid[K], wild[K];
     const float qn = __int_as_float(0x7fc00000);
     bool any_wild = false;
@@ -1166,14 +1167,12 @@ __global__ __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(BLOCK) v
         const int s = s0 + (wave * K + k) * 64 + lane;
         valid[k] = s < n;
         slot[k] = valid[k] ? (p.alist ? p.alist[s] : s) : 0;
-        ox[k] = oy[k] = oz[k] = bx[k] = by[k] = bz[k] = hx[k] = hy[k] = hz[k] = qn;
+        ox[k] = oy[k] = oz[k] = bx[k] = by[k] = bz[k] = qn;
         float g = qn;
         if (valid[k]) {
             ox[k] = p.job.ox[slot[k]]; oy[k] = p.job.oy[slot[k]]; oz[k] = p.job.oz[slot[k]];
             bx[k] = p.job.bx[slot[k]]; by[k] = p.job.by[slot[k]]; bz[k] = p.job.bz[slot[k]];
             g = p.job.g[slot[k]];
-            const float gg = fabsf(g);
-            hx[k] = p.job.dx[slot[k]] * gg; hy[k] = p.job.dy[slot[k]] * gg; hz[k] = p.job.dz[slot[k]] * gg;
         }
         wild[k] = valid[k] && !(g > 0.0f); // outside the records' range: in every band and slab
         any_wild = any_wild || wild[k];
@@ -1184,7 +1183,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(BLOCK) v
     int qcount = 0; // wave-uniform
     unsigned long long n_cand = 0, n_slow = 0;
 
-    // the reference arithmetic for queued (triangle, ray) pairs, one per lane
+    // the edge filter and the reference arithmetic for queued (triangle, ray) pairs, one per lane
     auto drain = [&](bool all) {
         while (qcount >= 64 || (all && qcount > 0)) {
             const int take = qcount >= 64 ? 64 : qcount;
@@ -1196,12 +1195,17 @@ __global__ __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(BLOCK) v
                 const int sl = p.alist ? p.alist[s] : s;
                 const v3 o = rtx::V(p.job.ox[sl], p.job.oy[sl], p.job.oz[sl]);
                 const v3 d = rtx::V(p.job.dx[sl], p.job.dy[sl], p.job.dz[sl]);
-                const v3 X = vpos(p.verts, 3 * tri), Y = vpos(p.verts, 3 * tri + 1), Z = vpos(p.verts, 3 * tri + 2);
-                float t;
-                if (rtx::ray_vs_triangle(o, d, X, Y, Z, t) && t > 0.0f) {
-                    const unsigned long long key =
-                        ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)(unsigned int)tri;
-                    atomicMin(&p.best[sl], key);
+                // the general edge filter first: most pairs inside a band miss their triangle
+                const float gg = fabsf(p.job.g[sl]);
+                if (rtf::filter_general(reinterpret_cast<const float *>(p.recs + tri), o.x, o.y, o.z, d.x * gg,
+                                        d.y * gg, d.z * gg) >= -1.0f) {
+                    const v3 X = vpos(p.verts, 3 * tri), Y = vpos(p.verts, 3 * tri + 1), Z = vpos(p.verts, 3 * tri + 2);
+                    float t;
+                    if (rtx::ray_vs_triangle(o, d, X, Y, Z, t) && t > 0.0f) {
+                        const unsigned long long key =
+                            ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)(unsigned int)tri;
+                        atomicMin(&p.best[sl], key);
+                    }
                 }
             }
         }
@@ -1249,15 +1253,10 @@ __global__ __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(BLOCK) v
                     if (tri < 0 || m1.w == 2.0f) continue; // padding / never accepted (wave-uniform)
                     const float Gu = u == 0 ? Ga : Gb;
                     if (!(any64(Gu < 1.0f) || wave_wild)) continue;
-                    const float4 *er4 = reinterpret_cast<const float4 *>(p.recs + tri);
-                    const float4 e0 = er4[0], e1 = er4[1], e2 = er4[2];
-                    const float er[12] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w, e2.x, e2.y, e2.z, e2.w};
 #pragma unroll
                     for (int k = 0; k < K; k++) {
                         const float t = u == 0 ? ta[k] : tb[k];
                         bool in = ((t < 1.0f) || wild[k]) && valid[k];
-                        if (any64(in))
-                            in = in && rtf::filter_general(er, ox[k], oy[k], oz[k], hx[k], hy[k], hz[k]) >= -1.0f;
                         const unsigned long long m = __builtin_amdgcn_ballot_w64(in);
                         if (m) {
                             n_cand += __popcll(m);
