@@ -53,8 +53,10 @@ struct rt_ctx {
     rtf::TriRec *rec_lights = nullptr; // RT_MAX_LIGHTS x rec_stride
     rtf::ConeRec *cone_camera = nullptr;
     rtf::ConeRec *cone_lights = nullptr; // RT_MAX_LIGHTS x rec_stride
-    rtf::ConeRec *ccone_camera = nullptr; // one per run of 32 slots
-    rtf::ConeRec *ccone_lights = nullptr; // RT_MAX_LIGHTS x rec_stride / 32
+    // per origin: one cone per run of RUN slots, then one per SUPER_RUN slots (ccone_stride records)
+    rtf::ConeRec *ccone_camera = nullptr;
+    rtf::ConeRec *ccone_lights = nullptr; // RT_MAX_LIGHTS x ccone_stride
+    size_t ccone_stride = 0, scone_offset = 0;
     int *slot_d = nullptr;                // triangle in each slot of the shared-origin traversal's order
     int num_slots = 0;
     size_t rec_stride = 0;
@@ -445,8 +447,10 @@ extern "C" int rt_set_mesh(rt_ctx *c, const rt_vertex *vertices, int num_vertice
         HIPCHK(c, hipMalloc(&c->rec_lights, RT_MAX_LIGHTS * c->rec_stride * sizeof(rtf::TriRec)));
         HIPCHK(c, hipMalloc(&c->cone_camera, c->rec_stride * sizeof(rtf::ConeRec)));
         HIPCHK(c, hipMalloc(&c->cone_lights, RT_MAX_LIGHTS * c->rec_stride * sizeof(rtf::ConeRec)));
-        HIPCHK(c, hipMalloc(&c->ccone_camera, (c->rec_stride / 32 + 1) * sizeof(rtf::ConeRec)));
-        HIPCHK(c, hipMalloc(&c->ccone_lights, RT_MAX_LIGHTS * (c->rec_stride / 32 + 1) * sizeof(rtf::ConeRec)));
+        c->scone_offset = c->rec_stride / RUN + 1;
+        c->ccone_stride = c->scone_offset + c->rec_stride / SUPER_RUN + 1;
+        HIPCHK(c, hipMalloc(&c->ccone_camera, c->ccone_stride * sizeof(rtf::ConeRec)));
+        HIPCHK(c, hipMalloc(&c->ccone_lights, RT_MAX_LIGHTS * c->ccone_stride * sizeof(rtf::ConeRec)));
         HIPCHK(c, hipMalloc(&c->ngroup_d, (ng + 1) * sizeof(float4)));
         HIPCHK(c, hipMalloc(&c->nrec_d, (ng * rtc::NGROUP + 1) * 2 * sizeof(float4)));
         HIPCHK(c, hipMalloc(&c->sphere_d, (nc + 1) * sizeof(float4)));
@@ -787,8 +791,11 @@ static int refresh_camera_recs(rt_ctx *c)
                            rtf::scene_extent(c->cam.pos, c->center, c->radius),
                            rtf::cone_reach_max(c->cam.pos, c->center, c->radius), c->rec_camera, c->cone_camera);
         HIPCHK(c, hipGetLastError());
-        hipLaunchKernelGGL(cluster_cone_kernel, dim3(cdiv(c->num_slots / 32, BLOCK)), dim3(BLOCK), 0, c->stream,
-                           (const rtf::ConeRec *)c->cone_camera, c->num_slots / 32, c->ccone_camera);
+        hipLaunchKernelGGL(cluster_cone_kernel, dim3(cdiv(c->num_slots / RUN, BLOCK)), dim3(BLOCK), 0, c->stream,
+                           (const rtf::ConeRec *)c->cone_camera, c->num_slots / RUN, RUN, c->ccone_camera);
+        hipLaunchKernelGGL(cluster_cone_kernel, dim3(cdiv(c->num_slots / SUPER_RUN, BLOCK)), dim3(BLOCK), 0, c->stream,
+                           (const rtf::ConeRec *)c->ccone_camera, c->num_slots / SUPER_RUN, SUPER_RUN / RUN,
+                           c->ccone_camera + c->scone_offset);
         HIPCHK(c, hipGetLastError());
     }
     c->camera_recs_dirty = false;
@@ -806,9 +813,13 @@ static int refresh_light_recs(rt_ctx *c)
                                c->rec_lights + (size_t)a * c->rec_stride,
                                c->cone_lights + (size_t)a * c->rec_stride);
             HIPCHK(c, hipGetLastError());
-            hipLaunchKernelGGL(cluster_cone_kernel, dim3(cdiv(c->num_slots / 32, BLOCK)), dim3(BLOCK), 0, c->stream,
-                               (const rtf::ConeRec *)(c->cone_lights + (size_t)a * c->rec_stride), c->num_slots / 32,
-                               c->ccone_lights + (size_t)a * (c->rec_stride / 32 + 1));
+            rtf::ConeRec *cc = c->ccone_lights + (size_t)a * c->ccone_stride;
+            hipLaunchKernelGGL(cluster_cone_kernel, dim3(cdiv(c->num_slots / RUN, BLOCK)), dim3(BLOCK), 0, c->stream,
+                               (const rtf::ConeRec *)(c->cone_lights + (size_t)a * c->rec_stride), c->num_slots / RUN,
+                               RUN, cc);
+            hipLaunchKernelGGL(cluster_cone_kernel, dim3(cdiv(c->num_slots / SUPER_RUN, BLOCK)), dim3(BLOCK), 0,
+                               c->stream, (const rtf::ConeRec *)cc, c->num_slots / SUPER_RUN, SUPER_RUN / RUN,
+                               cc + c->scone_offset);
             HIPCHK(c, hipGetLastError());
         }
     }
@@ -897,6 +908,7 @@ extern "C" int rt_intersect(rt_ctx *c)
             // shared origin: the records are in slot order; the all-pairs mode walks the mesh itself
             p.tri_of = (shared && !exact) ? c->slot_d : nullptr;
             p.ccones = (shared && c->trace_mode == RT_TRACE_CLUSTERED) ? c->ccone_camera : nullptr;
+            p.scones = p.ccones ? c->ccone_camera + c->scone_offset : nullptr;
             p.reach_max = (float)rtf::cone_reach_max(c->cam.pos, c->center, c->radius);
             p.dir_sign = 1.0f;
             memcpy(p.origin, c->cam.pos, sizeof p.origin);
@@ -988,9 +1000,9 @@ extern "C" int rt_color(rt_ctx *c)
                         p.recs = c->rec_lights + (size_t)a * c->rec_stride;
                         p.cones = c->cone_lights + (size_t)a * c->rec_stride;
                         p.tri_of = exact ? nullptr : c->slot_d;
-                        p.ccones = c->trace_mode == RT_TRACE_CLUSTERED
-                                       ? c->ccone_lights + (size_t)a * (c->rec_stride / 32 + 1)
-                                       : nullptr;
+                        p.ccones = c->trace_mode == RT_TRACE_CLUSTERED ? c->ccone_lights + (size_t)a * c->ccone_stride
+                                                                       : nullptr;
+                        p.scones = p.ccones ? p.ccones + c->scone_offset : nullptr;
                         p.reach_max = (float)rtf::cone_reach_max(c->lights[a].pos, c->center, c->radius);
                         p.dir_sign = -1.0f;
                         memcpy(p.origin, c->lights[a].pos, sizeof p.origin);

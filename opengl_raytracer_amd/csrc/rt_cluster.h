@@ -18,6 +18,9 @@
 namespace rtc {
 
 constexpr int CLUSTER = 32;
+using rtf::RUN;        // slots per run cone of the shared-origin traversal
+using rtf::SUPER_RUN;  // slots per cone of the level above: neighbouring clusters
+static_assert(CLUSTER % RUN == 0 && SUPER_RUN % CLUSTER == 0 && 1024 % SUPER_RUN == 0, "run sizes");
 
 struct ClusterSet {
     double S = 0.0;                      // the band records hold for rays with |o - X| <= S
@@ -38,9 +41,10 @@ struct ClusterSet {
     //   (n/theta, kappa/H), (n/H, triangle index as bits)
     // so that "in the band and in the slab" is  max(|n1.b|, |n2.o - kappa'|) < 1
     std::vector<float> nrecs;
-    // Order in which the shared-origin traversal visits the triangles: the clusters above, then
-    // every triangle that is in none of them in runs of CLUSTER, -1 where a run is short, padded
-    // with -1 to a whole number of 1024-record tiles.  Every triangle appears exactly once.
+    // Order in which the shared-origin traversal visits the triangles: the clusters above (each split
+    // once more into runs of RUN), neighbouring clusters per SUPER_RUN, -1 where a cluster
+    // is short; then every triangle that is in no cluster; padded with -1 to a whole number of
+    // 1024-record tiles.  Every triangle appears exactly once.
     std::vector<int32_t> slots;
     int num_ngroups = 0;
 };
@@ -126,6 +130,9 @@ inline void build(const rt_vertex *v, int num_tris, const float center[3], float
     }
 
     kd_order(regular, 0, regular.size(), CLUSTER, [&](int32_t t) { return &cen[(size_t)t * 3]; });
+    // one more split inside every leaf: the shared-origin traversal skips runs of RUN slots
+    for (size_t b = 0; b < regular.size(); b += CLUSTER)
+        kd_order(regular, b, std::min(regular.size(), b + CLUSTER), RUN, [&](int32_t t) { return &cen[(size_t)t * 3]; });
     const std::vector<int32_t> &keyed = regular;
     out.num_clusters = (int)((keyed.size() + CLUSTER - 1) / CLUSTER);
     out.spheres.assign((size_t)out.num_clusters * 4, 0.0f);
@@ -171,18 +178,23 @@ inline void build(const rt_vertex *v, int num_tris, const float center[3], float
     }
     build_normal_groups(out);
 
-    // Clusters are laid out with a large stride between neighbours in space, so that any
-    // contiguous part of the order (a chunk of the shadow traversal) samples the whole scene.
-    out.slots.assign(out.members.size(), -1);
+    // Groups of neighbouring clusters (a SUPER_RUN of slots) are laid out with a large stride
+    // between neighbours in space, so that any contiguous part of the order (a chunk of the shadow
+    // traversal) samples the whole scene.
     {
-        const size_t nc = (size_t)out.num_clusters;
-        size_t stride = nc / 8 + 1;
+        constexpr size_t PER = SUPER_RUN / CLUSTER;
+        const size_t nc = (size_t)out.num_clusters, ns = (nc + PER - 1) / PER;
+        out.slots.assign(ns * SUPER_RUN, -1);
+        size_t stride = ns / 8 + 1;
         auto gcd = [](size_t a, size_t b) { while (b) { size_t t = a % b; a = b; b = t; } return a; };
-        while (nc > 1 && gcd(stride, nc) != 1) stride++;
-        for (size_t j = 0; j < nc; j++) {
-            const size_t c = (j * stride) % nc;
-            std::copy(out.members.begin() + c * CLUSTER, out.members.begin() + (c + 1) * CLUSTER,
-                      out.slots.begin() + j * CLUSTER);
+        while (ns > 1 && gcd(stride, ns) != 1) stride++;
+        for (size_t j = 0; j < ns; j++) {
+            const size_t sc = (j * stride) % ns;
+            for (size_t q = 0; q < PER && sc * PER + q < nc; q++) {
+                const size_t c = sc * PER + q;
+                std::copy(out.members.begin() + c * CLUSTER, out.members.begin() + (c + 1) * CLUSTER,
+                          out.slots.begin() + j * SUPER_RUN + q * CLUSTER);
+            }
         }
     }
     std::vector<char> seen((size_t)num_tris, 0);

@@ -173,14 +173,17 @@ __global__ __launch_bounds__(BLOCK) void prep_origin_kernel(const rt_vertex *__r
     cones[i] = c;
 }
 
-// One cone per run of 32 slots that contains the cones of its members.
+// One cone per run of `len` consecutive cones that contains them all: run cones from the slots'
+// cones (len = RUN), cones of the level above from the run cones (len = SUPER_RUN / RUN).
+using rtf::RUN;
+using rtf::SUPER_RUN;
 __global__ __launch_bounds__(BLOCK) void cluster_cone_kernel(const rtf::ConeRec *__restrict__ cones, int num_runs,
-                                                             rtf::ConeRec *__restrict__ out)
+                                                             int len, rtf::ConeRec *__restrict__ out)
 {
     const int c = blockIdx.x * BLOCK + threadIdx.x;
     if (c >= num_runs) return;
     rtf::ConeRec r;
-    rtf::make_cluster_cone(cones + (size_t)c * 32, 32, &r);
+    rtf::make_cluster_cone(cones + (size_t)c * len, len, &r);
     out[c] = r;
 }
 
@@ -390,7 +393,8 @@ struct TraverseParams {
     int n;
     const rtf::TriRec *recs;
     const rtf::ConeRec *cones; // FORM 1 only
-    const rtf::ConeRec *ccones; // FORM 1: one cone per run of 32 slots, or nullptr (no skipping)
+    const rtf::ConeRec *ccones; // FORM 1: one cone per run of RUN slots, or nullptr (no skipping)
+    const rtf::ConeRec *scones; // FORM 1: one cone per SUPER_RUN slots (with ccones)
     const int *tri_of;          // FORM 1: triangle in each slot (-1: none), or nullptr (slot = triangle)
     const rt_vertex *verts;
     int num_tris;
@@ -475,7 +479,8 @@ __launch_bounds__(BLOCK) void traverse_kernel(TraverseParams p)
     // FORM 0: tiles of 256 edge records (12 KiB).  FORM 1: tiles of 1024 cone records (16 KiB);
     // the edge records are only touched by the rare second level and stay in global memory.
     __shared__ float4 lds4[FORM == 1 ? CONE_TILE : TILE * 3];
-    __shared__ float4 run4[FORM == 1 ? CONE_TILE / 32 : 1]; // FORM 1: the cones of the tile's 32 runs
+    __shared__ float4 run4[FORM == 1 ? CONE_TILE / RUN : 1];       // FORM 1: the cones of the tile's runs
+    __shared__ float4 sup4[FORM == 1 ? CONE_TILE / SUPER_RUN : 1]; // ... and of the level above
     constexpr int TSZ = (FORM == 1) ? CONE_TILE : TILE;
 
     const int tid = threadIdx.x;
@@ -643,12 +648,14 @@ __launch_bounds__(BLOCK) void traverse_kernel(TraverseParams p)
 #ifdef RT_DBG_TIMING
         const unsigned long long tt0 = __builtin_amdgcn_s_memtime();
 #endif
+        bool wave_decided = false;
         if (ANYHIT) {
             bool all_occ = true;
 #pragma unroll
             for (int k = 0; k < K; k++) all_occ = all_occ && occ[k];
             // barrier + early exit: leave when every ray of the workgroup is occluded
             if (__syncthreads_and(all_occ ? 1 : 0)) break;
+            wave_decided = !any64(!all_occ);
         } else {
             __syncthreads();
         }
@@ -661,9 +668,14 @@ __launch_bounds__(BLOCK) void traverse_kernel(TraverseParams p)
                 const bool have = p.tri_of ? (e < tile_n) : (e < tile_n && tile_base + e < p.num_tris);
                 lds4[e] = have ? cs[tile_base + e] : make_float4(0.0f, 0.0f, 0.0f, 2.0f);
             }
-            if (tid < CONE_TILE / 32) {
+            if (tid < CONE_TILE / RUN) {
                 const float4 *rc = reinterpret_cast<const float4 *>(p.ccones);
-                run4[tid] = (rc && tid * 32 < tile_n) ? rc[tile_base / 32 + tid] : make_float4(0.0f, 0.0f, 0.0f, -2.0f);
+                run4[tid] = (rc && tid * RUN < tile_n) ? rc[tile_base / RUN + tid] : make_float4(0.0f, 0.0f, 0.0f, -2.0f);
+            } else if (tid < CONE_TILE / RUN + CONE_TILE / SUPER_RUN) {
+                const int q = tid - CONE_TILE / RUN;
+                const float4 *sc = reinterpret_cast<const float4 *>(p.scones);
+                sup4[q] = (p.ccones && sc && q * SUPER_RUN < tile_n) ? sc[tile_base / SUPER_RUN + q]
+                                                                     : make_float4(0.0f, 0.0f, 0.0f, -2.0f);
             }
         } else {
             load_tile(lds4, p.recs, tile_base, p.num_tris, tid);
@@ -673,6 +685,8 @@ __launch_bounds__(BLOCK) void traverse_kernel(TraverseParams p)
 #ifdef RT_DBG_TIMING
         tm_tile += __builtin_amdgcn_s_memtime() - tt0;
 #endif
+        // a wavefront whose rays are all occluded only keeps the barriers company
+        if (ANYHIT && wave_decided) continue;
 
         if (EXACT) {
             for (int j = 0; j < tile_n; j++) {
@@ -707,14 +721,26 @@ __launch_bounds__(BLOCK) void traverse_kernel(TraverseParams p)
             // four triangles per step so that their LDS reads are in flight together.  Pairs
             // inside the cone are queued; full batches of 64 are handled with all lanes busy.
             for (int j = 0; j < CONE_TILE; j += 4) {
-                if ((j & 31) == 0) {
-                    // a run of 32 slots none of whose cones can hold a ray of this wavefront is skipped
-                    const float4 rc = run4[j >> 5];
+                if ((j & (SUPER_RUN - 1)) == 0) {
+                    // SUPER_RUN slots (neighbouring clusters) none of whose cones can hold a ray of this
+                    // wavefront are skipped ...
+                    const float4 rc = sup4[j / SUPER_RUN];
                     float G = fmaf(rc.z, bz[0], fmaf(rc.y, by[0], rc.x * bx[0]));
 #pragma unroll
                     for (int k = 1; k < K; k++) G = fmaxf(G, fmaf(rc.z, bz[k], fmaf(rc.y, by[k], rc.x * bx[k])));
                     if (!(any64(G >= rc.w) || wave_wild)) {
-                        j += 28;
+                        j += SUPER_RUN - 4;
+                        continue;
+                    }
+                }
+                if ((j & (RUN - 1)) == 0) {
+                    // ... and so is a run of RUN
+                    const float4 rc = run4[j / RUN];
+                    float G = fmaf(rc.z, bz[0], fmaf(rc.y, by[0], rc.x * bx[0]));
+#pragma unroll
+                    for (int k = 1; k < K; k++) G = fmaxf(G, fmaf(rc.z, bz[k], fmaf(rc.y, by[k], rc.x * bx[k])));
+                    if (!(any64(G >= rc.w) || wave_wild)) {
+                        j += RUN - 4;
                         continue;
                     }
 #ifdef RT_DBG_COUNT_RUNS
