@@ -62,6 +62,7 @@ struct rt_ctx {
     size_t rec_stride = 0;
     // clustered traversal of arbitrary rays: plane bands per triangle, spheres / member records per cluster
     float4 *ngroup_d = nullptr;
+    float4 *nsub_d = nullptr;
     float4 *nrec_d = nullptr;
     int num_ngroups = 0;
     float4 *sphere_d = nullptr;
@@ -330,6 +331,7 @@ extern "C" void rt_destroy(rt_ctx *c)
     (void)hipFree(c->ccone_lights);
     (void)hipFree(c->slot_d);
     (void)hipFree(c->ngroup_d);
+    (void)hipFree(c->nsub_d);
     (void)hipFree(c->nrec_d);
     (void)hipFree(c->sphere_d);
     (void)hipFree(c->crec_d);
@@ -371,6 +373,7 @@ extern "C" int rt_set_mesh(rt_ctx *c, const rt_vertex *vertices, int num_vertice
     (void)hipFree(c->slot_d); c->slot_d = nullptr;
     c->num_slots = 0;
     (void)hipFree(c->ngroup_d); c->ngroup_d = nullptr;
+    (void)hipFree(c->nsub_d); c->nsub_d = nullptr;
     (void)hipFree(c->nrec_d); c->nrec_d = nullptr;
     c->num_ngroups = 0;
     (void)hipFree(c->sphere_d); c->sphere_d = nullptr;
@@ -452,12 +455,15 @@ extern "C" int rt_set_mesh(rt_ctx *c, const rt_vertex *vertices, int num_vertice
         HIPCHK(c, hipMalloc(&c->ccone_camera, c->ccone_stride * sizeof(rtf::ConeRec)));
         HIPCHK(c, hipMalloc(&c->ccone_lights, RT_MAX_LIGHTS * c->ccone_stride * sizeof(rtf::ConeRec)));
         HIPCHK(c, hipMalloc(&c->ngroup_d, (ng + 1) * sizeof(float4)));
+        HIPCHK(c, hipMalloc(&c->nsub_d, (ng * (rtc::NGROUP / rtc::SUBGROUP) + 1) * sizeof(float4)));
         HIPCHK(c, hipMalloc(&c->nrec_d, (ng * rtc::NGROUP + 1) * 2 * sizeof(float4)));
         HIPCHK(c, hipMalloc(&c->sphere_d, (nc + 1) * sizeof(float4)));
         HIPCHK(c, hipMalloc(&c->crec_d, (nc * rtc::CLUSTER + 1) * sizeof(rtf::TriRec)));
         HIPCHK(c, hipMalloc(&c->member_d, (nc * rtc::CLUSTER + 1) * sizeof(int)));
         if (ng) {
             HIPCHK(c, hipMemcpyAsync(c->ngroup_d, cs.ngroups.data(), ng * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->nsub_d, cs.nsubs.data(), ng * (rtc::NGROUP / rtc::SUBGROUP) * sizeof(float4),
+                                     hipMemcpyHostToDevice, c->stream));
             HIPCHK(c, hipMemcpyAsync(c->nrec_d, cs.nrecs.data(), ng * rtc::NGROUP * 2 * sizeof(float4),
                                      hipMemcpyHostToDevice, c->stream));
         }
@@ -724,6 +730,7 @@ static int launch_traverse(rt_ctx *c, TraverseParams p, int n_upper, int form, b
 static int launch_traverse_clustered(rt_ctx *c, TraverseParams p, int n_upper, bool sorted)
 {
     p.ngroups = c->ngroup_d;
+    p.nsubs = c->nsub_d;
     p.nrecs = c->nrec_d;
     p.num_ngroups = c->num_ngroups;
     p.spheres = c->sphere_d;

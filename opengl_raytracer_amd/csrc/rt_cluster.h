@@ -34,6 +34,7 @@ struct ClusterSet {
     // triangles grouped by the direction of their normal: a ray's direction is in the band of a
     // member only if it is in the group's band (axis, w): |axis . b| < w
     std::vector<float> ngroups;          // 4 per group: axis, w (w = 2: every direction)
+    std::vector<float> nsubs;            // 4 per SUBGROUP members of a group: the same, tighter
     std::vector<rtf::BandRec> nbands;    // NGROUP per group: the member's own band record (theta = -1: padding)
     std::vector<rtf::SlabRec> nslabs;    // NGROUP per group: and its slab record
     std::vector<int32_t> nmembers;       // NGROUP per group: triangle index or -1
@@ -50,6 +51,7 @@ struct ClusterSet {
 };
 
 constexpr int NGROUP = 64;
+constexpr int SUBGROUP = 8; // the band sweep over sorted rays skips by these too (8: 2.82 ms per pass, 16: 2.89, none: 3.20)
 
 // Reorders idx[begin, end) so that consecutive runs of `leaf` elements are the leaves of a k-d
 // tree over the points pt(i) (3 doubles): split at the median rounded to a whole number of leaves,
@@ -211,9 +213,9 @@ inline void build(const rt_vertex *v, int num_tris, const float center[3], float
 }
 
 // Groups the triangles that have a band (theta >= 0) by normal direction.  Normals are folded onto
-// one hemisphere (n and -n give the same band), mapped to the unit square (octahedral map) and
-// sorted along a Morton curve; groups are runs of NGROUP.  Triangles whose band is everything
-// (theta = inf) form groups of their own with w = 2.
+// one hemisphere (n and -n give the same band) and split by medians (k-d order) into groups of
+// NGROUP, each again into parts of SUBGROUP.  Triangles whose band is everything (theta = inf)
+// form groups of their own with w = 2.
 inline void build_normal_groups(ClusterSet &cs)
 {
     const int n = (int)cs.bands.size();
@@ -229,14 +231,18 @@ inline void build_normal_groups(ClusterSet &cs)
         keyed.push_back(t);
     }
     kd_order(keyed, 0, keyed.size(), NGROUP, [&](int32_t t) { return &folded[(size_t)t * 3]; });
+    for (size_t b = 0; b < keyed.size(); b += NGROUP)
+        kd_order(keyed, b, std::min(keyed.size(), b + NGROUP), SUBGROUP, [&](int32_t t) { return &folded[(size_t)t * 3]; });
     const int g_reg = (int)((keyed.size() + NGROUP - 1) / NGROUP), g_alw = (int)((always.size() + NGROUP - 1) / NGROUP);
     cs.num_ngroups = g_reg + g_alw;
     cs.ngroups.assign((size_t)cs.num_ngroups * 4, 0.0f);
+    cs.nsubs.assign((size_t)cs.num_ngroups * (NGROUP / SUBGROUP) * 4, 0.0f);
+    for (size_t i = 3; i < cs.nsubs.size(); i += 4) cs.nsubs[i] = 2.0f; // until known better: every direction
     cs.nbands.assign((size_t)cs.num_ngroups * NGROUP, rtf::BandRec{{0.0f, 0.0f, 0.0f, -1.0f}});
     cs.nslabs.assign((size_t)cs.num_ngroups * NGROUP, rtf::SlabRec{{0.0f, INFINITY}});
     cs.nmembers.assign((size_t)cs.num_ngroups * NGROUP, -1);
-    for (int g = 0; g < g_reg; g++) {
-        const size_t b = (size_t)g * NGROUP, e = std::min(keyed.size(), b + NGROUP);
+    // (axis, w) such that a direction inside the band of any of keyed[b, e) satisfies |axis . b| < w
+    auto band_of = [&](size_t b, size_t e, float *out4) {
         const float *first = cs.bands[keyed[b]].v;
         double ax[3] = {0, 0, 0};
         for (size_t i = b; i < e; i++) {
@@ -266,10 +272,17 @@ inline void build_normal_groups(ClusterSet &cs)
         }
         float wf = (float)w;
         if ((double)wf < w) wf = std::nextafterf(wf, 4.0f);
-        cs.ngroups[(size_t)g * 4 + 0] = axf[0];
-        cs.ngroups[(size_t)g * 4 + 1] = axf[1];
-        cs.ngroups[(size_t)g * 4 + 2] = axf[2];
-        cs.ngroups[(size_t)g * 4 + 3] = wf;
+        out4[0] = axf[0]; out4[1] = axf[1]; out4[2] = axf[2]; out4[3] = wf;
+    };
+    for (int g = 0; g < g_reg; g++) {
+        const size_t b = (size_t)g * NGROUP, e = std::min(keyed.size(), b + NGROUP);
+        band_of(b, e, &cs.ngroups[(size_t)g * 4]);
+        for (size_t q = 0; q < NGROUP / SUBGROUP; q++) {
+            const size_t sb = b + q * SUBGROUP, se = std::min(e, sb + SUBGROUP);
+            float *o = &cs.nsubs[((size_t)g * (NGROUP / SUBGROUP) + q) * 4];
+            if (sb < se) band_of(sb, se, o);
+            else o[3] = 0.0f; // no member: |axis . b| < 0 never holds
+        }
         for (size_t i = b; i < e; i++) {
             cs.nbands[b + (i - b)] = cs.bands[keyed[i]];
             cs.nslabs[b + (i - b)] = cs.slabs[keyed[i]];

@@ -412,6 +412,7 @@ struct TraverseParams {
     // clustered traversal of arbitrary rays (traverse_cluster_kernel) only
     int sweeps;                 // host side: which instantiation of traverse_cluster_kernel (bit 0 = sweep A, bit 1 = sweep B)
     const float4 *ngroups;      // one (axis, w) per group of triangles with similar normals
+    const float4 *nsubs;        // one (axis, w) per SUBGROUP members of a group (traverse_band_kernel)
     const float4 *nrecs;        // the members, two float4 each: (n/theta, kappa/H), (n/H, triangle index);
                                 // inside the member's band and slab <=> max(|n1.b|, |n2.o - kappa'|) < 1
     int num_ngroups;
@@ -876,6 +877,7 @@ __launch_bounds__(BLOCK) void traverse_kernel(TraverseParams p)
 // ---------------------------------------------------------------------------
 constexpr int CLUSTER = 32;
 constexpr int NGROUP = 64;
+constexpr int SUBGROUP = 8;
 constexpr int GROUP_TILE = 512; // group records per LDS tile (8 KiB)
 
 template <int K, int SWEEPS>
@@ -1172,6 +1174,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(BLOCK) v
 {
     __shared__ float4 mem4[BAND_TILE_GROUPS * NGROUP * 2];
     __shared__ float4 grp4[BAND_TILE_GROUPS];
+    __shared__ float4 sub4[BAND_TILE_GROUPS * (NGROUP / SUBGROUP)];
     __shared__ unsigned int queue_all[(BLOCK / 64) * qcap(K)];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1247,6 +1250,8 @@ __global__ __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(BLOCK) v
             if (e < tile_g * NGROUP * 2) mem4[e] = src[e];
         }
         if (tid < tile_g) grp4[tid] = p.ngroups[tile_base + tid];
+        else if (tid >= 64 && tid - 64 < tile_g * (NGROUP / SUBGROUP))
+            sub4[tid - 64] = p.nsubs[(size_t)tile_base * (NGROUP / SUBGROUP) + (tid - 64)];
         __syncthreads();
         for (int gi = 0; gi < tile_g; gi++) {
             const float4 gc = grp4[gi];
@@ -1256,6 +1261,17 @@ __global__ __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(BLOCK) v
             if (!(any64(G < gc.w) || wave_wild)) continue; // no ray of the wavefront in the group's band
             const float4 *mrec = mem4 + gi * NGROUP * 2;
             for (int j = 0; j < NGROUP; j += 2) {
+                if ((j & (SUBGROUP - 1)) == 0) {
+                    // the same test for the part of the group that starts here
+                    const float4 sc = sub4[gi * (NGROUP / SUBGROUP) + j / SUBGROUP];
+                    float S = fabsf(fmaf(sc.z, bz[0], fmaf(sc.y, by[0], sc.x * bx[0])));
+#pragma unroll
+                    for (int k = 1; k < K; k++) S = fminf(S, fabsf(fmaf(sc.z, bz[k], fmaf(sc.y, by[k], sc.x * bx[k]))));
+                    if (!(any64(S < sc.w) || wave_wild)) {
+                        j += SUBGROUP - 2;
+                        continue;
+                    }
+                }
                 const float4 a1 = mrec[2 * j], a2 = mrec[2 * j + 1], b1 = mrec[2 * j + 2], b2 = mrec[2 * j + 3];
                 float ta[K], tb[K];
 #pragma unroll

@@ -180,7 +180,10 @@ extern "C" void fm_check_clustered(int n_tris, const float *verts, int n_rays, c
             if (group_of[k] >= 0) {
                 const float *G = &cs.ngroups[(size_t)group_of[k] * 4];
                 const float tg = fabsf(fmaf(G[2], bz, fmaf(G[1], by, G[0] * bx)));
-                if (tg < G[3] || wild) {
+                // the part of the group the member sits in (traverse_band_kernel tests it too)
+                const float *Q = &cs.nsubs[(size_t)(gpos[k] / rtc::SUBGROUP) * 4];
+                const float tq = fabsf(fmaf(Q[2], bz, fmaf(Q[1], by, Q[0] * bx)));
+                if ((tg < G[3] && tq < Q[3]) || wild) {
                     gp++;
                     const float *m = &cs.nrecs[(size_t)gpos[k] * 8];
                     const float t = fmaf(m[2], bz, fmaf(m[1], by, m[0] * bx));
@@ -212,8 +215,9 @@ extern "C" void fm_check_clustered(int n_tris, const float *verts, int n_rays, c
     stats[6] = bad; stats[7] = wildn; stats[8] = noclu; stats[9] = never;
 }
 
-// Cone of a run of 32 triangles (rt_filter.h make_cluster_cone) against the cones of its members:
-// whenever a member's float test passes for a direction, the run's test must pass too.
+// Cone of a run of 32 triangles (rt_filter.h make_cluster_cone) and the cone around four such cones
+// against the cones of the members: whenever a member's float test passes for a direction, the
+// run's test and the test of the level above must pass too.
 // stats: [0] (ray, run) pairs [1] run passes [2] (ray, member) passes [3] violations
 //        [4] runs whose cone is "everything" [5] runs whose cone is "nothing"
 extern "C" void fm_check_cluster_cone(int n_tris, const float *verts, int n_rays, const float *O, const float *dir,
@@ -236,6 +240,14 @@ extern "C" void fm_check_cluster_cone(int n_tris, const float *verts, int n_rays
         all += rc[c].v[3] == -2.0f;
         never += rc[c].v[3] == 2.0f;
     }
+    // the level above, as the traversal builds it: a cone around four run cones
+    const int supers = (runs + 3) / 4;
+    std::vector<rtf::ConeRec> rc4((size_t)supers * 4), sc(supers);
+    for (int c = 0; c < supers * 4; c++) {
+        if (c < runs) rc4[c] = rc[c];
+        else rtf::cone_never(&rc4[c]);
+    }
+    for (int q = 0; q < supers; q++) rtf::make_cluster_cone(&rc4[(size_t)q * 4], 4, &sc[q]);
     long long pairs = 0, rp = 0, mp = 0, bad = 0;
 #pragma omp parallel for reduction(+ : pairs, rp, mp, bad) schedule(static)
     for (int i = 0; i < n_rays; i++) {
@@ -244,7 +256,9 @@ extern "C" void fm_check_cluster_cone(int n_tris, const float *verts, int n_rays
         const float bx = d[0] * inv, by = d[1] * inv, bz = d[2] * inv;
         for (int c = 0; c < runs; c++) {
             const float tr = fmaf(rc[c].v[2], bz, fmaf(rc[c].v[1], by, rc[c].v[0] * bx));
-            const bool run_pass = tr >= rc[c].v[3];
+            const rtf::ConeRec &su = sc[c / 4];
+            const bool super_pass = fmaf(su.v[2], bz, fmaf(su.v[1], by, su.v[0] * bx)) >= su.v[3];
+            const bool run_pass = (tr >= rc[c].v[3]) && super_pass;
             pairs++;
             rp += run_pass;
             for (int j = 0; j < 32; j++) {
