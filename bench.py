@@ -214,7 +214,7 @@ def main():
                 share = a["pairs"] / max(sum(x["pairs"] for kk, x in groups.items() if kk[0] == 2), 1.0)
                 pairs = cnt["shadow_pairs"] * share
             name = ("closest_hit_kernel" if stage == 1 else "shade_kernel") + \
-                   f"<K={k},{('general', 'shared-origin', 'clustered')[form]}{',exact' if exact else ''}>"
+                   f"<K={k},{('general', 'shared-origin', 'clustered', 'shared-origin direction cells')[form]}{',exact' if exact else ''}>"
             if form == 2:
                 name = "closest_hit_kernel<clustered: traverse_band_kernel + traverse_cluster_kernel per pass>"
             a["launches"] = max(a["launches"], 1)

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include "../../include/rt.h"
 #include "rt_kernels.h"
@@ -71,6 +72,16 @@ struct rt_ctx {
     int num_clusters = 0;
     bool camera_recs_dirty = true;
     bool light_recs_dirty = true;
+    // direction cells (rt_grid.h): per shared origin (0 = camera, 1 + a = light a) the list offsets
+    // and the lists; grid_bits = 0 turns them off (RT_GRID_BITS)
+    int grid_bits = 8;
+    rtg::CellCone *cell_cones_d = nullptr;
+    unsigned int *grid_count_d = nullptr;
+    unsigned int *grid_off[1 + RT_MAX_LIGHTS] = {};
+    int *grid_entries[1 + RT_MAX_LIGHTS] = {};
+    size_t grid_cap[1 + RT_MAX_LIGHTS] = {};
+    void *scan_temp = nullptr;
+    size_t scan_temp_bytes = 0;
 
     uint32_t *tex = nullptr;
     int tex_w = 0, tex_h = 0;
@@ -280,13 +291,29 @@ extern "C" int rt_create(rt_ctx **out, int hip_device, int width, int height)
     }
     CRCHK(hipMalloc(&c->count_d, 8 * sizeof(int)));
     CRCHK(hipHostMalloc(&c->count_h, 8 * sizeof(int)));
+    if (const char *e = getenv("RT_GRID_BITS")) {
+        const int v = atoi(e);
+        if (v == 0 || (v >= 4 && v <= rtg::MAX_BITS)) c->grid_bits = v;
+    }
+    if (c->grid_bits) {
+        // the cells' bounding cones depend on the cell only: one table for every origin
+        const size_t ncells = (size_t)1 << (2 * c->grid_bits);
+        std::vector<rtg::CellCone> cc(ncells);
+        for (size_t i = 0; i < ncells; i++) rtg::make_cell_cone((uint32_t)i, c->grid_bits, &cc[i]);
+        CRCHK(hipMalloc(&c->cell_cones_d, ncells * sizeof(rtg::CellCone)));
+        CRCHK(hipMemcpy(c->cell_cones_d, cc.data(), ncells * sizeof(rtg::CellCone), hipMemcpyHostToDevice));
+        CRCHK(hipMalloc(&c->grid_count_d, (ncells + 1) * sizeof(unsigned int)));
+        CRCHK(rocprim::exclusive_scan(nullptr, c->scan_temp_bytes, c->grid_count_d, c->grid_count_d, 0u, ncells + 1,
+                                      rocprim::plus<unsigned int>()));
+        CRCHK(hipMalloc(&c->scan_temp, c->scan_temp_bytes + 256));
+    }
     CRCHK(hipMalloc(&c->fb_own, c->cap * sizeof(uint32_t)));
     CRCHK(hipMemsetAsync(c->fb_own, 0, c->cap * sizeof(uint32_t), c->stream));
     c->fb = c->fb_own;
     CRCHK(hipMalloc(&c->depth, c->cap * sizeof(float)));
     CRCHK(hipMemsetAsync(c->depth, 0, c->cap * sizeof(float), c->stream));
-    CRCHK(hipMalloc(&c->counters_d, 8 * sizeof(unsigned long long)));
-    CRCHK(hipMemsetAsync(c->counters_d, 0, 8 * sizeof(unsigned long long), c->stream));
+    CRCHK(hipMalloc(&c->counters_d, COUNTER_COPIES * 8 * sizeof(unsigned long long)));
+    CRCHK(hipMemsetAsync(c->counters_d, 0, COUNTER_COPIES * 8 * sizeof(unsigned long long), c->stream));
     for (int i = 0; i < rt_ctx::KLOG; i++) {
         CRCHK(hipEventCreate(&c->klog_ev[i].a));
         CRCHK(hipEventCreate(&c->klog_ev[i].b));
@@ -345,6 +372,13 @@ extern "C" void rt_destroy(rt_ctx *c)
     (void)hipFree(c->sort_iota);
     (void)hipFree(c->sort_slots);
     (void)hipFree(c->sort_temp);
+    (void)hipFree(c->cell_cones_d);
+    (void)hipFree(c->grid_count_d);
+    (void)hipFree(c->scan_temp);
+    for (int i = 0; i < 1 + RT_MAX_LIGHTS; i++) {
+        (void)hipFree(c->grid_off[i]);
+        (void)hipFree(c->grid_entries[i]);
+    }
     (void)hipFree(c->work);
     (void)hipFree(c->count_d);
     if (c->count_h) (void)hipHostFree(c->count_h);
@@ -790,6 +824,67 @@ static int launch_traverse_clustered(rt_ctx *c, TraverseParams p, int n_upper, b
     return klog_end(c, ks);
 }
 
+// Lists of the direction cells of one shared origin, from its cone records: count, scan, fill.
+// Reads the total back (one stream sync): runs when the camera or a light has moved, not per frame.
+static int build_grid(rt_ctx *c, int which, const rtf::ConeRec *cones, const rtf::ConeRec *ccones,
+                      const rtf::TriRec *recs, const float origin[3])
+{
+    const double reach_max = rtf::cone_reach_max(origin, c->center, c->radius);
+    const double extent = rtf::scene_extent(origin, c->center, c->radius);
+    if (!c->grid_bits || !c->num_slots) return RT_OK;
+    const size_t ncells = (size_t)1 << (2 * c->grid_bits);
+    if (!c->grid_off[which]) HIPCHK(c, hipMalloc(&c->grid_off[which], (ncells + 1) * sizeof(unsigned int)));
+    const float4 *cn = reinterpret_cast<const float4 *>(cones);
+    const float4 *rc = reinterpret_cast<const float4 *>(ccones);
+    const float4 *sc = reinterpret_cast<const float4 *>(ccones + c->scone_offset);
+    HIPCHK(c, hipMemsetAsync(c->grid_count_d + ncells, 0, sizeof(unsigned int), c->stream));
+    hipLaunchKernelGGL((grid_build_kernel<false>), dim3(cdiv((long long)ncells, BLOCK)), dim3(BLOCK), 0, c->stream,
+                       (const rtg::CellCone *)c->cell_cones_d, (int)ncells, cn, rc, sc, c->num_slots, recs,
+                       (const int *)c->slot_d, (const rt_vertex *)c->verts, origin[0], origin[1], origin[2], extent, reach_max,
+                       c->grid_count_d, (const unsigned int *)nullptr, (int *)nullptr);
+    HIPCHK(c, hipGetLastError());
+    size_t bytes = c->scan_temp_bytes;
+    HIPCHK(c, rocprim::exclusive_scan(c->scan_temp, bytes, c->grid_count_d, c->grid_off[which], 0u, ncells + 1,
+                                      rocprim::plus<unsigned int>(), c->stream));
+    unsigned int *total_h = reinterpret_cast<unsigned int *>(c->count_h + 4);
+    HIPCHK(c, hipMemcpyAsync(total_h, c->grid_off[which] + ncells, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const size_t total = *total_h;
+    if (total > c->grid_cap[which] || !c->grid_entries[which]) {
+        (void)hipFree(c->grid_entries[which]);
+        c->grid_entries[which] = nullptr;
+        c->grid_cap[which] = total + total / 4 + 1024;
+        HIPCHK(c, hipMalloc(&c->grid_entries[which], c->grid_cap[which] * sizeof(int)));
+    }
+    hipLaunchKernelGGL((grid_build_kernel<true>), dim3(cdiv((long long)ncells, BLOCK)), dim3(BLOCK), 0, c->stream,
+                       (const rtg::CellCone *)c->cell_cones_d, (int)ncells, cn, rc, sc, c->num_slots, recs,
+                       (const int *)c->slot_d, (const rt_vertex *)c->verts, origin[0], origin[1], origin[2], extent, reach_max,
+                       (unsigned int *)nullptr, (const unsigned int *)c->grid_off[which], c->grid_entries[which]);
+    if (getenv("RT_GRID_VERBOSE"))
+        fprintf(stderr, "rt: direction cells of origin %d: %zu cells, %zu list entries (%.1f per cell)\n", which, ncells,
+                total, (double)total / (double)ncells);
+    HIPCHK(c, hipGetLastError());
+    return RT_OK;
+}
+
+// One launch of the direction-cell traversal over the rays of a list.  stage: 1 closest hit, 2 shadow.
+static int launch_traverse_grid(rt_ctx *c, TraverseParams p, int n_upper, int which, bool anyhit, int stage)
+{
+    if (n_upper <= 0) return RT_OK;
+    p.grid_off = c->grid_off[which];
+    p.grid_entries = c->grid_entries[which];
+    p.grid_bits = c->grid_bits;
+    p.num_slots = c->num_slots;
+    size_t ks;
+    if (int r = klog_begin(c, stage, 3, 1, false, (unsigned long long)n_upper,
+                           (unsigned long long)n_upper * (unsigned long long)c->num_tris, &ks))
+        return r;
+    if (anyhit) hipLaunchKernelGGL((traverse_grid_kernel<true>), dim3(cdiv(n_upper, BLOCK)), dim3(BLOCK), 0, c->stream, p);
+    else hipLaunchKernelGGL((traverse_grid_kernel<false>), dim3(cdiv(n_upper, BLOCK)), dim3(BLOCK), 0, c->stream, p);
+    HIPCHK(c, hipGetLastError());
+    return klog_end(c, ks);
+}
+
 static int refresh_camera_recs(rt_ctx *c)
 {
     if (c->camera_recs_dirty && c->num_slots) {
@@ -804,6 +899,7 @@ static int refresh_camera_recs(rt_ctx *c)
                            (const rtf::ConeRec *)c->ccone_camera, c->num_slots / SUPER_RUN, SUPER_RUN / RUN,
                            c->ccone_camera + c->scone_offset);
         HIPCHK(c, hipGetLastError());
+        if (int r = build_grid(c, 0, c->cone_camera, c->ccone_camera, c->rec_camera, c->cam.pos)) return r;
     }
     c->camera_recs_dirty = false;
     return RT_OK;
@@ -828,6 +924,8 @@ static int refresh_light_recs(rt_ctx *c)
                                c->stream, (const rtf::ConeRec *)cc, c->num_slots / SUPER_RUN, SUPER_RUN / RUN,
                                cc + c->scone_offset);
             HIPCHK(c, hipGetLastError());
+            if (int r = build_grid(c, 1 + a, c->cone_lights + (size_t)a * c->rec_stride, cc,
+                                       c->rec_lights + (size_t)a * c->rec_stride, c->lights[a].pos)) return r;
         }
     }
     c->light_recs_dirty = false;
@@ -841,6 +939,11 @@ static int read_count(rt_ctx *c, int which, int *out)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     *out = c->count_h[which];
     return RT_OK;
+}
+
+static bool use_grid(const rt_ctx *c)
+{
+    return c->grid_bits > 0 && c->trace_mode == RT_TRACE_CLUSTERED && c->num_slots > 0;
 }
 
 static SharedOrigin shared_origin(rt_ctx *c, const float origin[3], float sign)
@@ -923,6 +1026,8 @@ extern "C" int rt_intersect(rt_ctx *c)
             p.tri_end = (shared && !exact) ? c->num_slots : c->num_tris;
             if (clustered) {
                 if (int r = launch_traverse_clustered(c, p, n_upper, sorted)) return r;
+            } else if (shared && use_grid(c)) {
+                if (int r = launch_traverse_grid(c, p, n_upper, 0, false, 1)) return r;
             } else if (int r = launch_traverse(c, p, n_upper, shared ? 1 : 0, false, 1)) {
                 return r;
             }
@@ -998,7 +1103,17 @@ extern "C" int rt_color(rt_ctx *c)
                     }
                     const int *acount = cnt0;
                     int pp = 0;
-                    for (int t0 = 0; t0 < n_trav; t0 += chunk) {
+                    if (use_grid(c)) {
+                        TraverseParams p{};
+                        fill_traverse_common(c, p);
+                        p.alist = alist;
+                        p.count = acount;
+                        p.n = n0;
+                        p.recs = c->rec_lights + (size_t)a * c->rec_stride;
+                        p.tri_of = c->slot_d;
+                        if (int r = launch_traverse_grid(c, p, n0, 1 + a, true, 2)) return r;
+                    }
+                    for (int t0 = 0; t0 < n_trav && !use_grid(c); t0 += chunk) {
                         TraverseParams p{};
                         fill_traverse_common(c, p);
                         p.alist = alist;
@@ -1131,9 +1246,13 @@ extern "C" int rt_get_counters(rt_ctx *c, uint64_t counters[8])
 {
     if (!c || !counters) return RT_ERR_ARG;
     if (int r = use_device(c)) return r;
-    HIPCHK(c, hipMemcpyAsync(counters, c->counters_d, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->counters_d, 0, 8 * sizeof(uint64_t), c->stream));
+    std::vector<uint64_t> copies((size_t)COUNTER_COPIES * 8);
+    HIPCHK(c, hipMemcpyAsync(copies.data(), c->counters_d, copies.size() * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                             c->stream));
+    HIPCHK(c, hipMemsetAsync(c->counters_d, 0, copies.size() * sizeof(uint64_t), c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 8; i++) counters[i] = 0;
+    for (size_t i = 0; i < copies.size(); i++) counters[i & 7] += copies[i];
     return RT_OK;
 }
 

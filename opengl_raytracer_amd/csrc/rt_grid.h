@@ -1,0 +1,188 @@
+// rt_grid.h -- direction cells around a shared origin.
+//
+// Every ray of a shared-origin launch (camera rays, shadow rays) is a direction seen from one
+// point O, and so is every triangle: a cone of directions (rt_filter.h, make_cone_rec) outside of
+// which the edge filter -- hence the reference -- rejects the pair.  The sphere of directions is
+// cut into G x G cells by the octahedral map; for each cell a list holds the slots whose cone
+// shares a direction with the cell.  A ray then looks at the list of its own cell only: what it
+// pays no longer depends on the number of triangles in the scene, nor on what its neighbours in
+// the wavefront look at.
+//
+// Conservativeness.  A ray with float-normalised direction b sits in cell oct_cell(b).  The build
+// lists slot k in cell c unless  angle(axis_c, axis_k) > psi_c + th_k,  where
+//   th_k  = acos(w_k/|a_k| - 2^-20) bounds the angle between a_k and any b that passes the float
+//           test  a_k . b >= w_k  (the same bound make_cluster_cone uses), and
+//   psi_c bounds the angle between axis_c and any direction whose EXACT octahedral coordinates lie
+//           within CELL_MARGIN of the cell's square; the float evaluation in oct_cell is off by
+//           less than 1e-6 of the square's side, CELL_MARGIN is 4e-6.
+// So a (ray, slot) pair missing from the ray's list fails the cone test, which is itself
+// conservative.  The walk down the cone hierarchy (cone per SUPER_RUN slots, per RUN slots, per
+// slot) uses the same test: those cones contain their members' cones by construction.
+//
+// Compiles for the device (hipcc) and for the host (tests/native/filter_model.cpp).
+#pragma once
+
+#include "rt_filter.h"
+
+namespace rtg {
+
+constexpr int MAX_BITS = 9;           // cells per axis = 2^bits
+constexpr double CELL_MARGIN = 4e-6;  // in units of the octahedral square [-1, 1]^2
+
+RT_HD uint32_t spread_bits(uint32_t a)
+{
+    a = (a | (a << 8)) & 0x00FF00FFu;
+    a = (a | (a << 4)) & 0x0F0F0F0Fu;
+    a = (a | (a << 2)) & 0x33333333u;
+    a = (a | (a << 1)) & 0x55555555u;
+    return a;
+}
+RT_HD uint32_t squeeze_bits(uint32_t a)
+{
+    a &= 0x55555555u;
+    a = (a | (a >> 1)) & 0x33333333u;
+    a = (a | (a >> 2)) & 0x0F0F0F0Fu;
+    a = (a | (a >> 4)) & 0x00FF00FFu;
+    a = (a | (a >> 8)) & 0x0000FFFFu;
+    return a;
+}
+
+// Cell of a direction: octahedral map onto [-1,1]^2, 2^bits cells per axis, the two cell
+// coordinates interleaved (Morton order: consecutive ids are neighbours).  Directions that are
+// zero, infinite or NaN land in cell 0; such rays pass no filter.
+RT_HD uint32_t oct_cell(float x, float y, float z, int bits)
+{
+    const float l1 = fabsf(x) + fabsf(y) + fabsf(z);
+    if (!(l1 > 0.0f) || !(l1 < INFINITY)) return 0u;
+    float u = x / l1, v = y / l1;
+    if (z < 0.0f) {
+        const float uu = (1.0f - fabsf(v)) * (u >= 0.0f ? 1.0f : -1.0f);
+        const float vv = (1.0f - fabsf(u)) * (v >= 0.0f ? 1.0f : -1.0f);
+        u = uu;
+        v = vv;
+    }
+    const float G = (float)(1u << bits);
+    const float qu = fminf(fmaxf(fmaf(u, 0.5f, 0.5f) * G, 0.0f), G - 1.0f);
+    const float qv = fminf(fmaxf(fmaf(v, 0.5f, 0.5f) * G, 0.0f), G - 1.0f);
+    return spread_bits((uint32_t)qu) | (spread_bits((uint32_t)qv) << 1);
+}
+
+// unit direction of a point of the octahedral square
+RT_HD void oct_decode(double u, double v, double d[3])
+{
+    const double au = fabs(u), av = fabs(v);
+    double x = u, y = v;
+    const double z = 1.0 - au - av;
+    if (z < 0.0) {
+        x = (1.0 - av) * (u >= 0.0 ? 1.0 : -1.0);
+        y = (1.0 - au) * (v >= 0.0 ? 1.0 : -1.0);
+    }
+    const double l = sqrt(x * x + y * y + z * z);
+    d[0] = x / l;
+    d[1] = y / l;
+    d[2] = z / l;
+}
+
+// Bounding cone of a cell: unit axis, cosine and sine of the half-angle psi.
+// A cell (2^bits per axis, bits >= 1) lies on one face of the octahedron, or is cut by the line
+// |u| + |v| = 1 through two of its corners into two triangles on two faces; either way it is a
+// union of flat convex polygons whose vertices are cell corners, so every direction of the cell is
+// within max_corner angle(axis, corner) of the axis.  Added to that: the angle a step of
+// CELL_MARGIN in (u, v) can make -- at most sqrt(6) CELL_MARGIN on the octahedron, whose points
+// are at least 1/sqrt(3) from the centre: 4.3 CELL_MARGIN; 8 CELL_MARGIN is used.
+struct CellCone {
+    double a[3];
+    double cpsi, spsi, psi;
+};
+
+RT_HD void make_cell_cone(uint32_t cell, int bits, CellCone *out)
+{
+    const uint32_t qu = squeeze_bits(cell), qv = squeeze_bits(cell >> 1);
+    const double G = (double)(1u << bits);
+    double cd[4][3], ax[3] = {0.0, 0.0, 0.0};
+    for (int k = 0; k < 4; k++) {
+        const double u = 2.0 * (double)(qu + (uint32_t)(k & 1)) / G - 1.0;
+        const double v = 2.0 * (double)(qv + (uint32_t)(k >> 1)) / G - 1.0;
+        oct_decode(u, v, cd[k]);
+        for (int i = 0; i < 3; i++) ax[i] += cd[k][i];
+    }
+    const double al = sqrt(rtf::dot3d(ax, ax));
+    for (int i = 0; i < 3; i++) out->a[i] = ax[i] / al;
+    double cmin = 1.0;
+    for (int k = 0; k < 4; k++) {
+        const double c = rtf::dot3d(out->a, cd[k]);
+        if (c < cmin) cmin = c;
+    }
+    if (cmin < -1.0) cmin = -1.0;
+    const double psi = acos(cmin) + 8.0 * CELL_MARGIN + 1e-6;
+    out->cpsi = cos(psi);
+    out->spsi = sin(psi);
+    out->psi = psi;
+}
+
+// Can a direction of the cell pass the float test of this cone record?  (See the header comment.)
+RT_HD bool cell_overlaps(const CellCone &cc, float cx, float cy, float cz, float cw)
+{
+    if (cw >= 2.0f) return false;      // nothing passes this record
+    if (!(cw > -2.0f)) return true;    // everything passes it (or NaN)
+    const double a[3] = {(double)cx, (double)cy, (double)cz};
+    const double al = sqrt(rtf::dot3d(a, a));
+    if (!(al > 0.0)) return true;
+    double ct = (double)cw / al - 9.5367431640625e-07; // 2^-20
+    if (!(ct > -0.5)) return true;     // half-angle beyond 2 rad: keep
+    if (ct > 1.0) ct = 1.0;
+    const double st = sqrt(1.0 - ct * ct);
+    const double c = rtf::dot3d(cc.a, a) / al;
+    // th + psi < pi here, where the cosine still decreases
+    return c >= ct * cc.cpsi - st * cc.spsi - 1e-9;
+}
+
+// Second, sharper test: the triangle's three edge planes against the cell.  With n_k, b_k as
+// make_cone_rec forms them from the ROUNDED edge record, the edge filter passes a direction d on the
+// triangle's side of the origin only if d . n_k >= b_k for all three edges.  Its other half (all
+// three <= +delta) holds the directions whose line meets the triangle BEHIND the origin; the
+// reference keeps 0 < t (<= tmax) only, and make_cone_rec's rules -- no vertex at O, O farther than
+// 2^-16 extent from the triangle's plane, edge records that are not degenerate -- are what makes the
+// computed t carry the true sign.  Those rules are checked again here, because a triangle seen
+// nearly edge-on has no cone (its grown spherical triangle is a long wedge) and yet perfectly good
+// edge planes: such a slot would otherwise sit in the list of every cell.  Every direction of the
+// cell is within psi of its axis A, so d . n_k <= A . n_k + psi: if that is below b_k for one edge,
+// no ray of the cell gets this slot past the edge filter and the reference's t > 0.
+// Returns true (keep the slot) whenever a rule fails.
+RT_HD bool cell_meets_edges(const CellCone &cc, const float X[3], const float Y[3], const float Z[3],
+                            const float O[3], const rtf::TriRec *edge, double scene_extent, double reach_max)
+{
+    if (!(edge->v[0] == edge->v[0])) return true; // NaN record: no ray passes it anyway
+    double p[3][3];
+    for (int i = 0; i < 3; i++) {
+        p[0][i] = (double)X[i] - (double)O[i];
+        p[1][i] = (double)Y[i] - (double)O[i];
+        p[2][i] = (double)Z[i] - (double)O[i];
+    }
+    for (int v = 0; v < 3; v++) {
+        const double l = sqrt(rtf::dot3d(p[v], p[v]));
+        if (!(l > 0.0) || !(l < 1e300)) return true;
+    }
+    double e1[3], e2[3], N[3];
+    for (int i = 0; i < 3; i++) { e1[i] = p[1][i] - p[0][i]; e2[i] = p[2][i] - p[0][i]; }
+    rtf::cross3d(e1, e2, N);
+    const double nl = sqrt(rtf::dot3d(N, N));
+    if (!(nl > 0.0)) return true;
+    const double h = fabs(rtf::dot3d(p[0], N)) / nl;
+    if (!(h > scene_extent * 1.52587890625e-05)) return true; // 2^-16
+    bool outside = false;
+    for (int k = 0; k < 3; k++) {
+        const double c[3] = {(double)edge->v[3 * k], (double)edge->v[3 * k + 1], (double)edge->v[3 * k + 2]};
+        const double cl = sqrt(rtf::dot3d(c, c));
+        const double sg = rtf::dot3d(c, p[k]); // sign only: the opposite vertex is inside
+        if (!(cl > 0.0) || !(cl < 1e300) || !(sg != 0.0)) return true;
+        const double delta = 3.0517578125e-05 * reach_max * 1.001 + 2.384185791015625e-07 * cl; // 2^-15, 2^-22
+        const double b = -delta / cl;
+        if (!(b > -0.5)) return true;
+        const double an = (sg > 0.0 ? 1.0 : -1.0) * rtf::dot3d(c, cc.a) / cl;
+        if (an + cc.psi + 1e-6 < b) outside = true;
+    }
+    return !outside;
+}
+
+} // namespace rtg

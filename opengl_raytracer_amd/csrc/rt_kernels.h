@@ -18,6 +18,7 @@
 #include "../../include/rt.h"
 #include "rt_exact.h"
 #include "rt_filter.h"
+#include "rt_grid.h"
 
 namespace rtk {
 
@@ -40,9 +41,13 @@ struct Camera {
 // counters (see rt_get_counters)
 enum { C_CH_RAYS = 0, C_SH_RAYS, C_CH_PAIRS, C_SH_PAIRS, C_CH_CAND, C_SH_CAND, C_CH_SLOW, C_SH_SLOW };
 
+// The eight counters are kept in COUNTER_COPIES copies, one 64-byte line each, picked by the
+// workgroup's index: atomics of one launch on one address are served one after the other (about 4 ns
+// each), which a launch of 10^5 wavefronts would otherwise wait for.  rt_get_counters adds the copies.
+constexpr int COUNTER_COPIES = 256;
 __device__ __forceinline__ void add_counter(unsigned long long *c, int which, unsigned long long v)
 {
-    if (v) atomicAdd(&c[which], v);
+    if (v) atomicAdd(&c[((blockIdx.x + blockIdx.y * 7u) % COUNTER_COPIES) * 8 + which], v);
 }
 
 // ---------------------------------------------------------------------------
@@ -409,6 +414,11 @@ struct TraverseParams {
     unsigned long long *best;
     int *occ;
     unsigned long long *counters;
+    // direction cells of the shared origin (traverse_grid_kernel) only
+    const unsigned int *grid_off; // first list entry of each cell; [number of cells] = total
+    const int *grid_entries;      // the lists: slots
+    int grid_bits;                // 2^bits cells per axis
+    int num_slots;
     // clustered traversal of arbitrary rays (traverse_cluster_kernel) only
     int sweeps;                 // host side: which instantiation of traverse_cluster_kernel (bit 0 = sweep A, bit 1 = sweep B)
     const float4 *ngroups;      // one (axis, w) per group of triangles with similar normals
@@ -856,6 +866,221 @@ __launch_bounds__(BLOCK) void traverse_kernel(TraverseParams p)
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// Direction cells (rt_grid.h): the list of every cell of a shared origin.
+// One thread per cell walks the cone hierarchy of the origin -- a cone per SUPER_RUN slots,
+// per RUN slots, per slot -- and keeps the slots whose cone shares a direction with the cell.
+// FILL = false counts (count[cell]), FILL = true writes the slots at off[cell].
+// ---------------------------------------------------------------------------
+template <bool FILL>
+__global__ __launch_bounds__(BLOCK) void grid_build_kernel(const rtg::CellCone *__restrict__ cells, int num_cells,
+                                                           const float4 *__restrict__ cones,
+                                                           const float4 *__restrict__ rcones,
+                                                           const float4 *__restrict__ scones, int num_slots,
+                                                           const rtf::TriRec *__restrict__ recs,
+                                                           const int *__restrict__ tri_of,
+                                                           const rt_vertex *__restrict__ verts, float ox, float oy,
+                                                           float oz, double extent, double reach_max,
+                                                           unsigned int *__restrict__ count,
+                                                           const unsigned int *__restrict__ off,
+                                                           int *__restrict__ entries)
+{
+    const int cell = blockIdx.x * BLOCK + threadIdx.x;
+    if (cell >= num_cells) return;
+    const rtg::CellCone cc = cells[cell];
+    unsigned int n = 0;
+    const unsigned int base = FILL ? off[cell] : 0u;
+    for (int s = 0; s < num_slots / SUPER_RUN; s++) {
+        const float4 sc = scones[s];
+        if (!rtg::cell_overlaps(cc, sc.x, sc.y, sc.z, sc.w)) continue;
+        for (int r = s * (SUPER_RUN / RUN); r < (s + 1) * (SUPER_RUN / RUN); r++) {
+            const float4 rc = rcones[r];
+            if (!rtg::cell_overlaps(cc, rc.x, rc.y, rc.z, rc.w)) continue;
+            for (int i = r * RUN; i < (r + 1) * RUN; i++) {
+                const float4 c = cones[i];
+                if (!rtg::cell_overlaps(cc, c.x, c.y, c.z, c.w)) continue;
+                {
+                    // the triangle's three edge planes against the cell
+                    const int tri = tri_of[i];
+                    const float O[3] = {ox, oy, oz};
+                    const rtf::TriRec er = recs[i];
+                    if (tri >= 0 && !rtg::cell_meets_edges(cc, verts[3 * tri].pos, verts[3 * tri + 1].pos,
+                                                           verts[3 * tri + 2].pos, O, &er, extent, reach_max))
+                        continue;
+                }
+                if (FILL) entries[base + n] = i;
+                n++;
+            }
+        }
+    }
+    if (!FILL) count[cell] = n;
+}
+
+// ---------------------------------------------------------------------------
+// Shared-origin traversal over direction cells.  One ray per lane; wavefronts are independent
+// (no barrier).  The rays of a wavefront are taken cell by cell: the cell's list is read 64 slots
+// at a time, ONE SLOT PER LANE (its edge record stays in the lane's registers), and every ray of
+// the cell is broadcast in turn (v_readlane) and put through the edge filter against the 64
+// records at once.  What a ray costs is therefore the length of its cell's list / 64, whatever the
+// other rays of the wavefront look at.  Survivors are queued per wavefront in LDS and go through the
+// reference arithmetic one pair per lane.
+//   ANYHIT false: closest hit, merged per ray by a 64-bit minimum of (t bits, triangle) in LDS,
+//                 then into p.best -- the same rule as traverse_kernel.
+//   ANYHIT true : shadow query; sets p.occ.  Rays found occluded leave their cell's loop.
+// Rays outside the range the cones were built for ("wild": job.g < 0) meet every slot.
+// grid = ray blocks of 256.
+// ---------------------------------------------------------------------------
+constexpr int GRID_QCAP = 320; // queue entries per wavefront; draining starts when fewer than 64 are free
+
+template <bool ANYHIT>
+__global__ __launch_bounds__(BLOCK) void traverse_grid_kernel(TraverseParams p)
+{
+    __shared__ unsigned long long best_all[ANYHIT ? 1 : BLOCK];
+    __shared__ int occ_all[ANYHIT ? BLOCK : 1];
+    // the rays as the reference arithmetic takes them: (origin, tmax), (direction, -)
+    __shared__ float4 ray_o_all[BLOCK], ray_d_all[BLOCK];
+    __shared__ unsigned int queue_all[(BLOCK / 64) * GRID_QCAP];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = p.count ? *p.count : p.n;
+    const int s = blockIdx.x * BLOCK + tid;
+    if (blockIdx.x * BLOCK + wave * 64 >= n) return; // the whole wavefront; no barriers below
+    unsigned long long *best = best_all + (ANYHIT ? 0 : wave * 64);
+    int *occl = occ_all + (ANYHIT ? wave * 64 : 0);
+    float4 *ray_o = ray_o_all + wave * 64, *ray_d = ray_d_all + wave * 64;
+    unsigned int *queue = queue_all + wave * GRID_QCAP;
+
+    bool valid = s < n;
+    const int sl = valid ? (p.alist ? p.alist[s] : s) : 0;
+    const float qn = __int_as_float(0x7fc00000);
+    float hx = qn, hy = qn, hz = qn, g = qn;
+    unsigned int cell = 0;
+    if (valid && ANYHIT && p.occ[sl] != 0) valid = false; // already decided (tmax not finite)
+    if (valid) {
+        const float bx = p.job.bx[sl], by = p.job.by[sl], bz = p.job.bz[sl];
+        g = p.job.g[sl];
+        const float gg = fabsf(g);
+        hx = bx * gg; hy = by * gg; hz = bz * gg;
+        cell = rtg::oct_cell(bx, by, bz, p.grid_bits);
+        ray_o[lane] = make_float4(p.job.ox[sl], p.job.oy[sl], p.job.oz[sl], ANYHIT ? p.job.tmax[sl] : 0.0f);
+        ray_d[lane] = make_float4(p.job.dx[sl], p.job.dy[sl], p.job.dz[sl], 0.0f);
+    }
+    // g is NaN for a ray that no filter passes (zero or non-finite direction or reach)
+    const bool live = valid && (g == g);
+    const bool wild = live && g < 0.0f;
+    if (ANYHIT) occl[lane] = 0;
+    else best[lane] = BEST_NONE;
+
+    int qcount = 0; // wave-uniform
+    unsigned long long n_cand = 0, n_slow = 0;
+
+    // the reference arithmetic on queued (triangle, ray) pairs, one per lane
+    auto drain = [&](bool all) {
+#ifdef RT_DBG_GRID_NO_DRAIN
+        n_cand += qcount;
+        qcount = 0;
+        return;
+#endif
+        while (qcount >= 64 || (all && qcount > 0)) {
+            const int take = qcount >= 64 ? 64 : qcount;
+            qcount -= take;
+            if (lane < take) {
+                const unsigned int e = queue[qcount + lane];
+                const int r = (int)(e & 63u);
+                const int tri = (int)(e >> 6);
+                if (!(ANYHIT && occl[r] != 0)) {
+                    const float4 ro = ray_o[r], rd = ray_d[r];
+                    const v3 o = rtx::V(ro.x, ro.y, ro.z), d = rtx::V(rd.x, rd.y, rd.z);
+                    const v3 X = vpos(p.verts, 3 * tri), Y = vpos(p.verts, 3 * tri + 1), Z = vpos(p.verts, 3 * tri + 2);
+                    float t;
+                    if (rtx::ray_vs_triangle(o, d, X, Y, Z, t)) {
+                        if (ANYHIT) {
+                            if (t > 0.0f && t <= ro.w) occl[r] = 1; // every writer writes 1
+                        } else if (t > 0.0f) {
+                            const unsigned long long key =
+                                ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)(unsigned int)tri;
+                            atomicMin(&best[r], key);
+                        }
+                    }
+                }
+            }
+            n_cand += take;
+        }
+    };
+
+    // the rays in `group` against the slots list[0 .. cnt) (list == nullptr: slots 0 .. cnt)
+    auto sweep = [&](const int *list, int cnt, unsigned long long group) {
+        for (int base = 0; base < cnt && group; base += 64) {
+            const int idx = base + lane;
+            int e = -1, tri = -1;
+            if (idx < cnt) e = list ? list[idx] : idx;
+            float4 r0 = make_float4(qn, qn, qn, qn), r1 = r0, r2 = r0;
+            if (e >= 0) {
+                const float4 *rp = reinterpret_cast<const float4 *>(p.recs + e);
+                r0 = rp[0]; r1 = rp[1]; r2 = rp[2];
+                tri = p.tri_of[e];
+            }
+            if (tri < 0) r0.x = qn; // an empty slot: no ray passes a NaN record
+            const float rec[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
+            unsigned long long m = group;
+#ifdef RT_DBG_GRID_NO_SWEEP
+            m = 0;
+#endif
+            while (m) {
+                const int r = __builtin_ctzll(m);
+                m &= m - 1;
+                const float rx = readlane_f(hx, r), ry = readlane_f(hy, r), rz = readlane_f(hz, r);
+                float lo, hi;
+                rtf::filter_origin_lohi(rec, rx, ry, rz, lo, hi);
+                const bool pass = fmaxf(lo, -hi) >= -1.0f;
+                const unsigned long long h = __builtin_amdgcn_ballot_w64(pass);
+                if (h) {
+                    if (pass) queue[qcount + lanes_below(h)] = ((unsigned int)tri << 6) | (unsigned int)r;
+                    qcount += __popcll(h);
+                    if (qcount > GRID_QCAP - 64) drain(false);
+                }
+            }
+            n_slow += __popcll(group);
+            if (ANYHIT && __popcll(group) >= 8) {
+                // worth a partly filled batch: rays found occluded skip the rest of the list
+                drain(true);
+                group &= ~__builtin_amdgcn_ballot_w64(occl[lane] != 0);
+            }
+        }
+    };
+
+    unsigned long long remaining = __builtin_amdgcn_ballot_w64(live && !wild);
+    while (remaining) {
+        const int leader = __builtin_ctzll(remaining);
+        const unsigned int c0 = (unsigned int)__builtin_amdgcn_readlane((int)cell, leader);
+        const unsigned long long group = __builtin_amdgcn_ballot_w64(cell == c0) & remaining;
+        remaining &= ~group;
+        const unsigned int off = p.grid_off[c0];
+        const int cnt = (int)(p.grid_off[c0 + 1] - off);
+        sweep(p.grid_entries + off, cnt, group);
+    }
+    const unsigned long long wilds = __builtin_amdgcn_ballot_w64(wild);
+    if (wilds) sweep(nullptr, p.num_slots, wilds);
+    drain(true);
+
+    if (lane == 0) {
+        add_counter(p.counters, ANYHIT ? C_SH_CAND : C_CH_CAND, n_cand);
+        add_counter(p.counters, ANYHIT ? C_SH_SLOW : C_CH_SLOW, n_slow);
+        if (wave == 0) {
+            const int mine = min(BLOCK, n - blockIdx.x * BLOCK);
+            add_counter(p.counters, ANYHIT ? C_SH_PAIRS : C_CH_PAIRS,
+                        (unsigned long long)mine * (unsigned long long)p.num_tris);
+        }
+    }
+    if (!valid) return;
+    if (ANYHIT) {
+        if (occl[lane] != 0) p.occ[sl] = 1;
+    } else {
+        const unsigned long long key = best[lane];
+        if (key != BEST_NONE) atomicMin(&p.best[sl], key);
+    }
+}
 
 // ---------------------------------------------------------------------------
 // Clustered closest-hit traversal of arbitrary rays (bounce passes).  Same result as
@@ -1451,7 +1676,8 @@ __global__ __launch_bounds__(BLOCK) void shadow_setup_kernel(const int *__restri
     job.tmax[slot] = dist;
     s.occ[slot] = (dist < INFINITY) ? 0 : 1; // `lightRay.t > d` can only hold for finite d
     prepare_shared(job, slot, o2, ld, so.origin, so.center, so.radius, so.reach_max, so.sign);
-    if (keys) keys[slot] = direction_key(ld.x, ld.y, ld.z);
+    // sorted by the cell of the direction in which the light sees them (rt_grid.h), 10 bits per axis
+    if (keys) keys[slot] = rtg::oct_cell(-ld.x, -ld.y, -ld.z, 10);
 }
 
 // spheres of the shadow trace, then raycol_cs.glsl:50-79 for the rays that reach the light

@@ -1,0 +1,33 @@
+"""Times every rank's share of a bench frame on one GPU for several row-tile heights: the slowest
+rank bounds the strong-scaling efficiency (usage: WORLD=8 TILE_ROWS=16,32,64 python tools/diag_tiles.py)."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.getcwd())
+import opengl_raytracer_amd as rt
+from bench import workload, setup_scene
+
+wl = workload(sys.argv[1] if len(sys.argv) > 1 else "soup64k_4k_p6")
+world = int(os.environ.get("WORLD", "8"))
+g = rt.RayTracer(wl["width"], wl["height"])
+setup_scene(g, wl)
+
+
+def share(tile_rows, rank, world):
+    g.set_row_tiles(tile_rows, rank, world)
+    g.render(wl["passes"]); g.sync()
+    t0 = time.perf_counter()
+    for _ in range(2):
+        g.render(wl["passes"])
+    g.sync()
+    return (time.perf_counter() - t0) / 2 * 1e3
+
+
+base = share(wl["height"], 0, 1)
+print("whole frame %.2f ms" % base, flush=True)
+for tr in [int(x) for x in os.environ.get("TILE_ROWS", "16,32,64,128").split(",")]:
+    ms = [share(tr, r, world) for r in range(world)]
+    print("world %d tile_rows %d: max %.2f mean %.2f ms -> speedup %.2fx  %s" %
+          (world, tr, max(ms), sum(ms) / len(ms), base / max(ms), [round(m, 1) for m in ms]), flush=True)
+g.close()
