@@ -272,3 +272,84 @@ extern "C" void fm_check_cluster_cone(int n_tris, const float *verts, int n_rays
     }
     stats[0] = pairs; stats[1] = rp; stats[2] = mp; stats[3] = bad; stats[4] = all; stats[5] = never;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Direction cells (rt_grid.h), as grid_build_kernel + traverse_grid_kernel evaluate them: a pair
+// reaches the reference arithmetic iff the triangle is on the list of the ray's cell -- its cone
+// record and its three edge planes both meet the cell, and so do the cones of its run of 16 and of
+// the four runs above it -- or the ray is outside the cones' validity (wild), AND the edge filter
+// passes.  The triangles are taken in the given order, 16 per run, 64 per cone of the level above.
+// stats: [0] pairs [1] pairs on the cell's list [2] pairs reaching the reference arithmetic
+//        [3] oracle accepts [4] violations [5] pairs the cone + edge filter cascade lets through
+//        [6] wild rays [7] listed pairs whose run or upper cone misses the cell (must be 0)
+// ---------------------------------------------------------------------------------------------
+#include "../../opengl_raytracer_amd/csrc/rt_grid.h"
+
+extern "C" void fm_check_grid(int n_tris, const float *verts, int n_rays, const float *O, const float *org,
+                              const float *dir, const float *tmax, const float *center, float radius, float sign,
+                              int bits, long long *stats)
+{
+    const double extent = rtf::scene_extent(O, center, radius);
+    const double rmax = rtf::cone_reach_max(O, center, radius);
+    const float rmaxf = (float)rmax;
+    const int runs = (n_tris + 15) / 16, supers = (runs + 3) / 4;
+    std::vector<rtf::TriRec> recs((size_t)supers * 64);
+    std::vector<rtf::ConeRec> cones((size_t)supers * 64), rc((size_t)supers * 4), sc(supers);
+    for (int k = 0; k < supers * 64; k++) {
+        if (k >= n_tris) { rtf::nan_rec(&recs[k]); rtf::cone_never(&cones[k]); continue; }
+        const float *X = verts + 9 * k, *Y = X + 3, *Z = X + 6;
+        rtf::make_origin_rec(X, Y, Z, O, &recs[k]);
+        rtf::make_cone_rec(X, Y, Z, O, &recs[k], extent, rmax, &cones[k]);
+    }
+    for (int r = 0; r < supers * 4; r++) rtf::make_cluster_cone(&cones[(size_t)r * 16], 16, &rc[r]);
+    for (int q = 0; q < supers; q++) rtf::make_cluster_cone(&rc[(size_t)q * 4], 4, &sc[q]);
+    // per ray: unit direction, scale, cell cone
+    std::vector<rtg::CellCone> cc(n_rays);
+    std::vector<float> bb((size_t)n_rays * 4);
+    std::vector<char> wild(n_rays);
+    long long wildn = 0;
+    for (int i = 0; i < n_rays; i++) {
+        const float *o = org + 3 * i, *d = dir + 3 * i;
+        const float reach = rtf::reach_shared(O, o, center, radius);
+        const float inv = sign / sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        const float bx = d[0] * inv, by = d[1] * inv, bz = d[2] * inv;
+        bb[4 * i] = bx; bb[4 * i + 1] = by; bb[4 * i + 2] = bz;
+        bb[4 * i + 3] = rtf::dir_scale(reach, bx, by, bz);
+        wild[i] = !(reach <= rmaxf);
+        wildn += wild[i];
+        rtg::make_cell_cone(rtg::oct_cell(bx, by, bz, bits), bits, &cc[i]);
+    }
+    long long pairs = 0, listed_n = 0, p2 = 0, acc = 0, bad = 0, old_n = 0, hier = 0;
+#pragma omp parallel for reduction(+ : pairs, listed_n, p2, acc, bad, old_n, hier) schedule(static)
+    for (int k = 0; k < n_tris; k++) {
+        const float *X = verts + 9 * k, *Y = X + 3, *Z = X + 6;
+        const rtf::ConeRec &cone = cones[k], &rcone = rc[k / 16], &scone = sc[k / 64];
+        for (int i = 0; i < n_rays; i++) {
+            const float *o = org + 3 * i, *d = dir + 3 * i;
+            const float bx = bb[4 * i], by = bb[4 * i + 1], bz = bb[4 * i + 2], g = fabsf(bb[4 * i + 3]);
+            bool listed = rtg::cell_overlaps(cc[i], cone.v[0], cone.v[1], cone.v[2], cone.v[3]) &&
+                          rtg::cell_meets_edges(cc[i], X, Y, Z, O, &recs[k], extent, rmax);
+            if (listed) {
+                const bool up = rtg::cell_overlaps(cc[i], rcone.v[0], rcone.v[1], rcone.v[2], rcone.v[3]) &&
+                                rtg::cell_overlaps(cc[i], scone.v[0], scone.v[1], scone.v[2], scone.v[3]);
+                hier += !up;
+                listed = up; // the build never reaches a slot whose run it has skipped
+            }
+            const bool edge = rtf::filter_origin(recs[k].v, bx * g, by * g, bz * g) >= -1.0f;
+            const bool reach_exact = (listed || wild[i]) && edge;
+            const float dt = fmaf(cone.v[2], bz, fmaf(cone.v[1], by, cone.v[0] * bx));
+            const bool old_path = ((dt >= cone.v[3]) || wild[i]) && edge;
+            float t;
+            bool a = rto_ray_vs_triangle(o, d, X, Y, Z, &t) != 0 && t > 0.0f;
+            if (a && tmax) a = t <= tmax[i];
+            pairs++;
+            listed_n += listed;
+            p2 += reach_exact;
+            old_n += old_path;
+            acc += a;
+            bad += (a && !reach_exact);
+        }
+    }
+    stats[0] = pairs; stats[1] = listed_n; stats[2] = p2; stats[3] = acc; stats[4] = bad; stats[5] = old_n;
+    stats[6] = wildn; stats[7] = hier;
+}

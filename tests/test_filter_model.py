@@ -518,3 +518,161 @@ def test_run_cones_with_degenerate_always_and_unsorted_members(fm):
     fin = np.isfinite(dirs).all(1)
     st = run_cluster_cone(fm, tris, O, dirs[fin], 1.0)
     assert st["bad"] == 0 and st["everything"] >= 1, st
+
+
+# ---------------------------------------------------------------------------------------------
+# Direction cells: the per-cell triangle lists of the shared-origin traversal
+# ---------------------------------------------------------------------------------------------
+def run_grid(fm, tris, O, org, dirs, sign, tmax=None, bits=8):
+    c, r = bounding_sphere(tris)
+    stats = (C.c_longlong * 8)()
+    tris = np.ascontiguousarray(tris, dtype=f32)
+    O = np.ascontiguousarray(O, dtype=f32)
+    org = np.ascontiguousarray(org, dtype=f32)
+    dirs = np.ascontiguousarray(dirs, dtype=f32)
+    tm = None if tmax is None else np.ascontiguousarray(tmax, dtype=f32)
+    fm.fm_check_grid.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_void_p]
+    fm.fm_check_grid(tris.shape[0], tris.ctypes.data, org.shape[0], O.ctypes.data, org.ctypes.data,
+                     dirs.ctypes.data, tm.ctypes.data if tm is not None else None, c.ctypes.data, r, sign, bits, stats)
+    return dict(zip(["pairs", "listed", "both", "accepts", "bad", "cascade", "wild", "hier"], list(stats)))
+
+
+def shadow_rays_towards(rs, tris, L, extent, per_tri=6, far=None):
+    """Shadow rays as shadow_setup_kernel forms them, from surface points behind triangle features."""
+    _, dirs = rays_through_features(rs, tris, L[None, :].astype(np.float64), per_tri=per_tri)
+    dist = rs.uniform(0.05, 5.0, (dirs.shape[0], 1)) * extent if far is None else far
+    p = (L[None, :].astype(np.float64) + dirs.astype(np.float64) * dist).astype(f32)
+    dlt = (L[None, :] - p).astype(f32)
+    inv = (f32(1.0) / np.sqrt((dlt * dlt).sum(1, dtype=f32))).astype(f32)
+    ld = (dlt * inv[:, None]).astype(f32)
+    org = (p + ld * f32(0.0000001)).astype(f32)
+    pm = (p - ld * f32(0.0000001)).astype(f32)
+    tmax = np.sqrt(((L[None, :] - pm) ** 2).sum(1, dtype=f32)).astype(f32)
+    return org, ld, tmax
+
+
+@pytest.mark.parametrize("bits", [4, 8, 9])
+@pytest.mark.parametrize("sc", SCENES, ids=[s["name"] for s in SCENES])
+def test_direction_cells_primary_rays(fm, sc, bits):
+    rs = np.random.RandomState(91)
+    tris = spatially_sorted(tris_random(rs, 1536, sc["extent"], sc["size"], sc["offset"]))
+    for trial in range(2):
+        O = (rs.uniform(-3, 3, 3) * sc["extent"] + np.asarray(sc["offset"])).astype(f32)
+        _, dirs = rays_through_features(rs, tris, O[None, :].astype(np.float64))
+        org = (O[None, :] + dirs * f32(0.001)).astype(f32)
+        st = run_grid(fm, tris, O, org, dirs, 1.0, bits=bits)
+        assert st["bad"] == 0 and st["hier"] == 0, st
+        assert st["accepts"] > 1000 and st["wild"] == 0, st
+        if sc["name"] == "soup" and bits >= 8:
+            # the lists are short: far fewer pairs than the cone test alone lets through to the edge filter
+            assert st["listed"] < 0.01 * st["pairs"], st
+
+
+def test_direction_cells_rays_on_cell_borders_and_octahedron_seams(fm):
+    """Directions on the grid lines of the octahedral map, on the fold |u|+|v| = 1, on the axes and
+    on the seams of the lower hemisphere, a few ulps either side."""
+    rs = np.random.RandomState(92)
+    tris = spatially_sorted(tris_random(rs, 2048, 1.0, 0.08))
+    O = f32([0.05, -0.02, 0.03])                     # inside the soup: triangles in every direction
+    n = 6000
+    G = 256.0
+    u = (np.round(rs.uniform(-1, 1, n) * G / 2) * 2 / G)            # on grid lines
+    v = rs.uniform(-1, 1, n)
+    swap = rs.rand(n) < 0.5
+    u, v = np.where(swap, v, u), np.where(swap, u, v)
+    fold = rs.rand(n) < 0.25                                        # on the fold between the hemispheres
+    v = np.where(fold, np.sign(v) * (1 - np.abs(u)), v)
+    seam = rs.rand(n) < 0.15                                        # border of the square: lower-hemisphere seams
+    u = np.where(seam, np.sign(u) + (u == 0), u)
+    d = np.empty((n, 3))
+    z = 1 - np.abs(u) - np.abs(v)
+    lower = z < 0
+    d[:, 0] = np.where(lower, (1 - np.abs(v)) * np.where(u >= 0, 1, -1), u)
+    d[:, 1] = np.where(lower, (1 - np.abs(u)) * np.where(v >= 0, 1, -1), v)
+    d[:, 2] = z
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d += rs.normal(size=d.shape) * 10.0 ** rs.uniform(-9, -6, (n, 1))
+    axes = np.concatenate([np.eye(3), -np.eye(3)]).repeat(20, 0) + rs.normal(size=(120, 3)) * 1e-8
+    d = np.concatenate([d, axes]).astype(f32)
+    _, aimed = rays_through_features(rs, tris, O[None, :].astype(np.float64), per_tri=2)
+    d = np.concatenate([d, aimed])
+    org = (O[None, :] + d * f32(0.001)).astype(f32)
+    for bits in (8, 9):
+        st = run_grid(fm, tris, O, org, d, 1.0, bits=bits)
+        assert st["bad"] == 0 and st["hier"] == 0, st
+        assert st["accepts"] > 1000, st
+
+
+def test_direction_cells_nasty_triangles_and_origins_on_planes(fm):
+    rs = np.random.RandomState(93)
+    tris = tris_nasty(rs, 2048, 2.0)
+    n = 300
+    xy = rs.uniform(-2, 2, (n, 3, 2))
+    floor = np.concatenate([xy, np.zeros((n, 3, 1))], axis=2).astype(f32)
+    O = f32([0.25, -0.5, 0.0])                       # in the floor's plane
+    floor[0, 0] = O
+    tris = np.concatenate([floor, tris])
+    for origin in (O, f32([0.1, -0.2, 0.3]), f32([5.0, 1.0, -2.0])):
+        _, dirs = rays_through_features(rs, tris, origin[None, :].astype(np.float64))
+        fin = np.isfinite(dirs).all(1)
+        dirs = dirs[fin]
+        org = (origin[None, :] + dirs * f32(0.001)).astype(f32)
+        st = run_grid(fm, tris, origin, org, dirs, 1.0)
+        assert st["bad"] == 0 and st["hier"] == 0 and st["accepts"] > 1000, st
+
+
+def test_direction_cells_edge_on_slivers_leave_the_lists(fm):
+    """Triangles seen nearly edge-on have no cone; their edge planes still keep them out of the lists
+    of cells that look elsewhere."""
+    rs = np.random.RandomState(94)
+    O = f32([0.0, 0.0, -3.0])
+    n = 512
+    c = rs.uniform(-1, 1, (n, 3))
+    tris = np.empty((n, 3, 3))
+    for i in range(n):
+        toward = c[i] - O
+        toward /= np.linalg.norm(toward)
+        side = np.cross(toward, rs.normal(size=3))
+        side /= np.linalg.norm(side)
+        # spanned by the viewing direction and one sideways vector: the plane misses the origin by 1e-3..1e-2
+        lift = np.cross(toward, side) * 10.0 ** rs.uniform(-3, -2)
+        tris[i] = [c[i] + lift, c[i] + 0.08 * toward + lift, c[i] + 0.05 * side + 0.04 * toward + lift]
+    tris = tris.astype(f32)
+    _, dirs = rays_through_features(rs, tris, O[None, :].astype(np.float64))
+    org = (O[None, :] + dirs * f32(0.001)).astype(f32)
+    st = run_grid(fm, tris, O, org, dirs, 1.0)
+    assert st["bad"] == 0 and st["hier"] == 0 and st["accepts"] > 200, st
+    # every ray here is aimed at one of the slivers, whose wedges are long; without the plane test all pairs are listed
+    assert st["listed"] < 0.3 * st["pairs"], st
+
+
+@pytest.mark.parametrize("sc", SCENES[:3], ids=[s["name"] for s in SCENES[:3]])
+def test_direction_cells_shadow_rays(fm, sc):
+    rs = np.random.RandomState(95)
+    tris = spatially_sorted(tris_random(rs, 1536, sc["extent"], sc["size"], sc["offset"]))
+    L = (rs.uniform(-3, 3, 3) * sc["extent"] + np.asarray(sc["offset"])).astype(f32)
+    org, ld, tmax = shadow_rays_towards(rs, tris, L, sc["extent"])
+    st = run_grid(fm, tris, L, org, ld, -1.0, tmax)
+    assert st["bad"] == 0 and st["hier"] == 0, st
+    assert st["accepts"] > 300, st
+
+
+def test_direction_cells_light_near_surfaces_and_wild_rays(fm):
+    rs = np.random.RandomState(96)
+    L = f32([0.3, 0.1, -0.2])
+    tris = tris_random(rs, 1024, 1.0, 0.3)
+    for i in range(200):   # planes through (or a hair off) the light
+        a, b = rs.normal(size=3), rs.normal(size=3)
+        off = rs.normal(size=3) * 10.0 ** rs.uniform(-9, -4)
+        c = rs.uniform(-1, 1, 2)
+        tris[i] = (L + off + np.array([c[0] * a + c[1] * b + 0.3 * rs.normal() * a,
+                                       c[0] * a + c[1] * b + 0.3 * rs.normal() * b,
+                                       c[0] * a + c[1] * b - 0.3 * rs.normal() * (a + b)])).astype(f32)
+    org, ld, tmax = shadow_rays_towards(rs, tris, L, 1.0)
+    st = run_grid(fm, tris, L, org, ld, -1.0, tmax)
+    assert st["bad"] == 0 and st["hier"] == 0, st
+    # rays that start far outside the scene bound meet every slot
+    org, ld, _ = shadow_rays_towards(rs, tris, L, 1.0, per_tri=2, far=500.0)
+    st = run_grid(fm, tris, L, org, ld, -1.0, np.full(ld.shape[0], 1e9, dtype=f32))
+    assert st["bad"] == 0 and st["wild"] == ld.shape[0], st

@@ -357,7 +357,8 @@ def test_stage_timers_and_counters(rt):
         log = g.kernel_log()
         assert [int(x) for x in log["stage"]] == [1, 2, 1, 2]
         assert (log["ms"] > 0).all() and (log["pairs"] > 0).all()
-        assert log["form"][0] == 1 and log["form"][2] == 2   # fresh rays share the camera origin; bounce rays: clustered
+        # fresh rays share the camera origin (direction cells), shadow rays the light; bounce rays: clustered
+        assert log["form"][0] == 3 and log["form"][1] == 3 and log["form"][2] == 2
         assert g.kernel_log().shape[0] == 0
 
 
