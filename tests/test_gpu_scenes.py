@@ -77,7 +77,7 @@ def test_small_mesh_default_threshold(rt, oracle_mod, host, monkeypatch):
         assert not bad.any(), describe_mismatch(got, want, bad)
         assert np.array_equal(g.read_pixels(), c.read_pixels())
         forms = [int(r["form"]) for r in g.kernel_log() if int(r["stage"]) == 1]
-        assert forms == [1, 0], forms
+        assert forms == [3, 0], forms   # primary rays: direction cells; bounce rays: per-pair filter
 
 
 def test_frame_loop_program(rt, oracle_mod, host, tmp_path):
