@@ -82,6 +82,10 @@ struct rt_ctx {
     size_t grid_cap[1 + RT_MAX_LIGHTS] = {};
     void *scan_temp = nullptr;
     size_t scan_temp_bytes = 0;
+    rtg::SlotView *slot_views_d = nullptr; // scratch of the list builder, one per slot
+    // direction cells of the band sweep: lists of member records, per mesh
+    unsigned int *band_off = nullptr;
+    int *band_entries = nullptr;
 
     uint32_t *tex = nullptr;
     int tex_w = 0, tex_h = 0;
@@ -296,14 +300,18 @@ extern "C" int rt_create(rt_ctx **out, int hip_device, int width, int height)
         if (v == 0 || (v >= 4 && v <= rtg::MAX_BITS)) c->grid_bits = v;
     }
     if (c->grid_bits) {
-        // the cells' bounding cones depend on the cell only: one table for every origin
+        // the cells' bounding cones depend on the cell only: one table (every level) for every origin
         const size_t ncells = (size_t)1 << (2 * c->grid_bits);
-        std::vector<rtg::CellCone> cc(ncells);
-        for (size_t i = 0; i < ncells; i++) rtg::make_cell_cone((uint32_t)i, c->grid_bits, &cc[i]);
-        CRCHK(hipMalloc(&c->cell_cones_d, ncells * sizeof(rtg::CellCone)));
-        CRCHK(hipMemcpy(c->cell_cones_d, cc.data(), ncells * sizeof(rtg::CellCone), hipMemcpyHostToDevice));
-        CRCHK(hipMalloc(&c->grid_count_d, (ncells + 1) * sizeof(unsigned int)));
-        CRCHK(rocprim::exclusive_scan(nullptr, c->scan_temp_bytes, c->grid_count_d, c->grid_count_d, 0u, ncells + 1,
+        const size_t nall = rtg::level_offset(c->grid_bits) + ncells;
+        std::vector<rtg::CellCone> cc(nall);
+        for (int l = rtg::MIN_LEVEL; l <= c->grid_bits; l++)
+            for (size_t i = 0; i < ((size_t)1 << (2 * l)); i++)
+                rtg::make_cell_cone((uint32_t)i, l, &cc[rtg::level_offset(l) + i]);
+        CRCHK(hipMalloc(&c->cell_cones_d, nall * sizeof(rtg::CellCone)));
+        CRCHK(hipMemcpy(c->cell_cones_d, cc.data(), nall * sizeof(rtg::CellCone), hipMemcpyHostToDevice));
+        // per cell, plus the list "everywhere", plus one for the scan's total
+        CRCHK(hipMalloc(&c->grid_count_d, (ncells + 2) * sizeof(unsigned int)));
+        CRCHK(rocprim::exclusive_scan(nullptr, c->scan_temp_bytes, c->grid_count_d, c->grid_count_d, 0u, ncells + 2,
                                       rocprim::plus<unsigned int>()));
         CRCHK(hipMalloc(&c->scan_temp, c->scan_temp_bytes + 256));
     }
@@ -375,6 +383,9 @@ extern "C" void rt_destroy(rt_ctx *c)
     (void)hipFree(c->cell_cones_d);
     (void)hipFree(c->grid_count_d);
     (void)hipFree(c->scan_temp);
+    (void)hipFree(c->band_off);
+    (void)hipFree(c->band_entries);
+    (void)hipFree(c->slot_views_d);
     for (int i = 0; i < 1 + RT_MAX_LIGHTS; i++) {
         (void)hipFree(c->grid_off[i]);
         (void)hipFree(c->grid_entries[i]);
@@ -387,6 +398,33 @@ extern "C" void rt_destroy(rt_ctx *c)
     (void)hipFree(c->counters_d);
     if (c->stream_own) (void)hipStreamDestroy(c->stream_own);
     delete c;
+}
+
+// Lists of the band sweep's direction cells, from the member records of the mesh: count, scan, fill.
+static int scan_cell_counts(rt_ctx *c, unsigned int *off, size_t *total);
+static int build_band_cells(rt_ctx *c)
+{
+    if (!c->grid_bits || !c->num_ngroups) return RT_OK;
+    const size_t ncells = (size_t)1 << (2 * c->grid_bits);
+    const int members = c->num_ngroups * rtc::NGROUP;
+    const dim3 grid((unsigned)(((long long)members * BUILD_TOP_CELLS + BLOCK - 1) / BLOCK));
+    HIPCHK(c, hipMalloc(&c->band_off, (ncells + 2) * sizeof(unsigned int)));
+    HIPCHK(c, hipMemsetAsync(c->grid_count_d, 0, (ncells + 2) * sizeof(unsigned int), c->stream));
+    hipLaunchKernelGGL((band_build_kernel<false>), grid, dim3(BLOCK), 0, c->stream,
+                       (const rtg::CellCone *)c->cell_cones_d, c->grid_bits, (const float4 *)c->nrec_d, members,
+                       c->grid_count_d, (const unsigned int *)nullptr, (int *)nullptr);
+    HIPCHK(c, hipGetLastError());
+    size_t total = 0;
+    if (int r = scan_cell_counts(c, c->band_off, &total)) return r;
+    HIPCHK(c, hipMalloc(&c->band_entries, (total + 64) * sizeof(int)));
+    hipLaunchKernelGGL((band_build_kernel<true>), grid, dim3(BLOCK), 0, c->stream,
+                       (const rtg::CellCone *)c->cell_cones_d, c->grid_bits, (const float4 *)c->nrec_d, members,
+                       c->grid_count_d, (const unsigned int *)c->band_off, c->band_entries);
+    HIPCHK(c, hipGetLastError());
+    if (getenv("RT_GRID_VERBOSE"))
+        fprintf(stderr, "rt: direction cells of the band sweep: %zu cells, %zu list entries (%.1f per cell)\n", ncells,
+                total, (double)total / (double)ncells);
+    return RT_OK;
 }
 
 extern "C" int rt_set_mesh(rt_ctx *c, const rt_vertex *vertices, int num_vertices)
@@ -413,6 +451,9 @@ extern "C" int rt_set_mesh(rt_ctx *c, const rt_vertex *vertices, int num_vertice
     (void)hipFree(c->sphere_d); c->sphere_d = nullptr;
     (void)hipFree(c->crec_d); c->crec_d = nullptr;
     (void)hipFree(c->member_d); c->member_d = nullptr;
+    (void)hipFree(c->band_off); c->band_off = nullptr;
+    (void)hipFree(c->band_entries); c->band_entries = nullptr;
+    (void)hipFree(c->slot_views_d); c->slot_views_d = nullptr;
     c->num_clusters = 0;
     c->num_vertices = num_vertices;
     c->num_tris = num_vertices / 3;
@@ -509,6 +550,7 @@ extern "C" int rt_set_mesh(rt_ctx *c, const rt_vertex *vertices, int num_vertice
                                      hipMemcpyHostToDevice, c->stream));
         }
         HIPCHK(c, hipStreamSynchronize(c->stream)); // the host vectors go out of scope
+        if (int r = build_band_cells(c)) return r;
     }
     c->have_mesh = true;
     c->camera_recs_dirty = true;
@@ -774,7 +816,23 @@ static int launch_traverse_clustered(rt_ctx *c, TraverseParams p, int n_upper, b
     const int tiles = cdiv(p.tri_end - p.tri_begin, TILE);
     if (n_upper <= 0 || tiles <= 0) return RT_OK;
     size_t ks;
-    if (sorted) {
+    if (c->band_entries) {
+        // sweep A over the direction cells (sorted rays share cells, any order gives the same result),
+        // then sweep B
+        TraverseParams a = p;
+        a.alist = sorted ? c->sort_slots : nullptr;
+        if (sorted) { a.count = nullptr; a.n = n_upper; }
+        a.band_off = c->band_off;
+        a.band_entries = c->band_entries;
+        a.grid_bits = c->grid_bits;
+        if (int r = klog_begin(c, 1, 2, 1, false, (unsigned long long)n_upper,
+                               (unsigned long long)n_upper * (unsigned long long)(p.tri_end - p.tri_begin), &ks))
+            return r;
+        hipLaunchKernelGGL(traverse_bandcell_kernel, dim3(cdiv(n_upper, BLOCK)), dim3(BLOCK), 0, c->stream, a);
+        HIPCHK(c, hipGetLastError());
+        if (int r = klog_end(c, ks)) return r;
+        p.sweeps = 2;
+    } else if (sorted) {
         {
             TraverseParams a = p;
             a.alist = c->sort_slots;
@@ -811,7 +869,7 @@ static int launch_traverse_clustered(rt_ctx *c, TraverseParams p, int n_upper, b
     p.tiles_per_y = (p.tiles_per_y + CONE_TILE / TILE - 1) / (CONE_TILE / TILE) * (CONE_TILE / TILE);
     const dim3 grid(ray_blocks, cdiv(tiles, p.tiles_per_y));
     if (int r = klog_begin(c, 1, 2, k, false, (unsigned long long)n_upper,
-                           sorted ? 0ull : (unsigned long long)n_upper * (unsigned long long)(p.tri_end - p.tri_begin), &ks))
+                           p.sweeps == 2 ? 0ull : (unsigned long long)n_upper * (unsigned long long)(p.tri_end - p.tri_begin), &ks))
         return r;
     if (p.sweeps == 2) {
         if (k == 2) hipLaunchKernelGGL((traverse_cluster_kernel<2, 2>), grid, dim3(BLOCK), 0, c->stream, p);
@@ -824,46 +882,58 @@ static int launch_traverse_clustered(rt_ctx *c, TraverseParams p, int n_upper, b
     return klog_end(c, ks);
 }
 
-// Lists of the direction cells of one shared origin, from its cone records: count, scan, fill.
-// Reads the total back (one stream sync): runs when the camera or a light has moved, not per frame.
-static int build_grid(rt_ctx *c, int which, const rtf::ConeRec *cones, const rtf::ConeRec *ccones,
-                      const rtf::TriRec *recs, const float origin[3])
+// count[] -> off[] (exclusive scan over the cells, the list "everywhere" and one more entry that
+// receives the total); reads the total back (one stream sync) and clears count[] for the fill pass
+static int scan_cell_counts(rt_ctx *c, unsigned int *off, size_t *total)
 {
-    const double reach_max = rtf::cone_reach_max(origin, c->center, c->radius);
-    const double extent = rtf::scene_extent(origin, c->center, c->radius);
-    if (!c->grid_bits || !c->num_slots) return RT_OK;
     const size_t ncells = (size_t)1 << (2 * c->grid_bits);
-    if (!c->grid_off[which]) HIPCHK(c, hipMalloc(&c->grid_off[which], (ncells + 1) * sizeof(unsigned int)));
-    const float4 *cn = reinterpret_cast<const float4 *>(cones);
-    const float4 *rc = reinterpret_cast<const float4 *>(ccones);
-    const float4 *sc = reinterpret_cast<const float4 *>(ccones + c->scone_offset);
-    HIPCHK(c, hipMemsetAsync(c->grid_count_d + ncells, 0, sizeof(unsigned int), c->stream));
-    hipLaunchKernelGGL((grid_build_kernel<false>), dim3(cdiv((long long)ncells, BLOCK)), dim3(BLOCK), 0, c->stream,
-                       (const rtg::CellCone *)c->cell_cones_d, (int)ncells, cn, rc, sc, c->num_slots, recs,
-                       (const int *)c->slot_d, (const rt_vertex *)c->verts, origin[0], origin[1], origin[2], extent, reach_max,
-                       c->grid_count_d, (const unsigned int *)nullptr, (int *)nullptr);
-    HIPCHK(c, hipGetLastError());
     size_t bytes = c->scan_temp_bytes;
-    HIPCHK(c, rocprim::exclusive_scan(c->scan_temp, bytes, c->grid_count_d, c->grid_off[which], 0u, ncells + 1,
+    HIPCHK(c, rocprim::exclusive_scan(c->scan_temp, bytes, c->grid_count_d, off, 0u, ncells + 2,
                                       rocprim::plus<unsigned int>(), c->stream));
     unsigned int *total_h = reinterpret_cast<unsigned int *>(c->count_h + 4);
-    HIPCHK(c, hipMemcpyAsync(total_h, c->grid_off[which] + ncells, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(total_h, off + ncells + 1, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->grid_count_d, 0, (ncells + 2) * sizeof(unsigned int), c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    const size_t total = *total_h;
+    *total = *total_h;
+    return RT_OK;
+}
+
+// Lists of the direction cells of one shared origin, from its cone and edge records: count, scan,
+// fill.  Runs when the camera or a light has moved, not per frame.
+static int build_grid(rt_ctx *c, int which, const rtf::ConeRec *cones, const rtf::TriRec *recs, const float origin[3])
+{
+    if (!c->grid_bits || !c->num_slots) return RT_OK;
+    const double reach_max = rtf::cone_reach_max(origin, c->center, c->radius);
+    const double extent = rtf::scene_extent(origin, c->center, c->radius);
+    const size_t ncells = (size_t)1 << (2 * c->grid_bits);
+    if (!c->grid_off[which]) HIPCHK(c, hipMalloc(&c->grid_off[which], (ncells + 2) * sizeof(unsigned int)));
+    const float4 *cn = reinterpret_cast<const float4 *>(cones);
+    if (!c->slot_views_d) HIPCHK(c, hipMalloc(&c->slot_views_d, (size_t)c->num_slots * sizeof(rtg::SlotView)));
+    hipLaunchKernelGGL(slot_view_kernel, dim3(cdiv(c->num_slots, BLOCK)), dim3(BLOCK), 0, c->stream, cn, c->num_slots,
+                       recs, (const int *)c->slot_d, (const rt_vertex *)c->verts, origin[0], origin[1], origin[2], extent,
+                       reach_max, c->slot_views_d);
+    HIPCHK(c, hipGetLastError());
+    const dim3 grid(cdiv((long long)c->num_slots * BUILD_TOP_CELLS, BLOCK));
+    HIPCHK(c, hipMemsetAsync(c->grid_count_d, 0, (ncells + 2) * sizeof(unsigned int), c->stream));
+    hipLaunchKernelGGL((grid_build_kernel<false>), grid, dim3(BLOCK), 0, c->stream,
+                       (const rtg::CellCone *)c->cell_cones_d, c->grid_bits, (const rtg::SlotView *)c->slot_views_d,
+                       c->num_slots, c->grid_count_d, (const unsigned int *)nullptr, (int *)nullptr);
+    HIPCHK(c, hipGetLastError());
+    size_t total = 0;
+    if (int r = scan_cell_counts(c, c->grid_off[which], &total)) return r;
     if (total > c->grid_cap[which] || !c->grid_entries[which]) {
         (void)hipFree(c->grid_entries[which]);
         c->grid_entries[which] = nullptr;
         c->grid_cap[which] = total + total / 4 + 1024;
         HIPCHK(c, hipMalloc(&c->grid_entries[which], c->grid_cap[which] * sizeof(int)));
     }
-    hipLaunchKernelGGL((grid_build_kernel<true>), dim3(cdiv((long long)ncells, BLOCK)), dim3(BLOCK), 0, c->stream,
-                       (const rtg::CellCone *)c->cell_cones_d, (int)ncells, cn, rc, sc, c->num_slots, recs,
-                       (const int *)c->slot_d, (const rt_vertex *)c->verts, origin[0], origin[1], origin[2], extent, reach_max,
-                       (unsigned int *)nullptr, (const unsigned int *)c->grid_off[which], c->grid_entries[which]);
+    hipLaunchKernelGGL((grid_build_kernel<true>), grid, dim3(BLOCK), 0, c->stream,
+                       (const rtg::CellCone *)c->cell_cones_d, c->grid_bits, (const rtg::SlotView *)c->slot_views_d,
+                       c->num_slots, c->grid_count_d, (const unsigned int *)c->grid_off[which], c->grid_entries[which]);
+    HIPCHK(c, hipGetLastError());
     if (getenv("RT_GRID_VERBOSE"))
         fprintf(stderr, "rt: direction cells of origin %d: %zu cells, %zu list entries (%.1f per cell)\n", which, ncells,
                 total, (double)total / (double)ncells);
-    HIPCHK(c, hipGetLastError());
     return RT_OK;
 }
 
@@ -899,7 +969,7 @@ static int refresh_camera_recs(rt_ctx *c)
                            (const rtf::ConeRec *)c->ccone_camera, c->num_slots / SUPER_RUN, SUPER_RUN / RUN,
                            c->ccone_camera + c->scone_offset);
         HIPCHK(c, hipGetLastError());
-        if (int r = build_grid(c, 0, c->cone_camera, c->ccone_camera, c->rec_camera, c->cam.pos)) return r;
+        if (int r = build_grid(c, 0, c->cone_camera, c->rec_camera, c->cam.pos)) return r;
     }
     c->camera_recs_dirty = false;
     return RT_OK;
@@ -924,7 +994,7 @@ static int refresh_light_recs(rt_ctx *c)
                                c->stream, (const rtf::ConeRec *)cc, c->num_slots / SUPER_RUN, SUPER_RUN / RUN,
                                cc + c->scone_offset);
             HIPCHK(c, hipGetLastError());
-            if (int r = build_grid(c, 1 + a, c->cone_lights + (size_t)a * c->rec_stride, cc,
+            if (int r = build_grid(c, 1 + a, c->cone_lights + (size_t)a * c->rec_stride,
                                        c->rec_lights + (size_t)a * c->rec_stride, c->lights[a].pos)) return r;
         }
     }

@@ -95,6 +95,16 @@ struct CellCone {
     double cpsi, spsi, psi;
 };
 
+// Tables hold the cones of every level from MIN_LEVEL to `bits`, level by level:
+// level l starts at level_offset(l) and has 4^l cells; a cell's children are 4 cell + {0,1,2,3}.
+constexpr int MIN_LEVEL = 2;
+RT_HD size_t level_offset(int level)
+{
+    size_t o = 0;
+    for (int l = MIN_LEVEL; l < level; l++) o += (size_t)1 << (2 * l);
+    return o;
+}
+
 RT_HD void make_cell_cone(uint32_t cell, int bits, CellCone *out)
 {
     const uint32_t qu = squeeze_bits(cell), qv = squeeze_bits(cell >> 1);
@@ -120,7 +130,100 @@ RT_HD void make_cell_cone(uint32_t cell, int bits, CellCone *out)
     out->psi = psi;
 }
 
-// Can a direction of the cell pass the float test of this cone record?  (See the header comment.)
+// What the list builder needs to know about one slot, formed once per slot and origin:
+//   the cone record as (unit axis, cos th, sin th) with th = acos(w/|a| - 2^-20), the bound on the
+//   angle between the axis and any direction that passes the record's float test; and
+//   the triangle's three edge planes (n_k, b_k) as make_cone_rec forms them from the ROUNDED edge
+//   record.  The edge filter passes a direction d on the triangle's side of the origin only if
+//   d . n_k >= b_k for all three edges.  Its other half (all three <= +delta) holds the directions
+//   whose line meets the triangle BEHIND the origin; the reference keeps 0 < t (<= tmax) only, and
+//   make_cone_rec's rules -- no vertex at O, O farther than 2^-16 extent from the triangle's plane,
+//   edge records that are not degenerate -- are what makes the computed t carry the true sign.
+//   Those rules are checked again here (planes = false when one fails), because a triangle seen
+//   nearly edge-on has no cone (its grown spherical triangle is a long wedge) and yet perfectly
+//   good edge planes: without them such a slot would sit in the list of every cell.
+struct SlotView {
+    int cone;      // 0: no direction passes the record, 1: a proper cone, 2: every direction passes
+    bool planes;   // the edge planes below are valid
+    double a[3], ct, st;
+    double n[3][3], b[3];
+};
+
+RT_HD void make_slot_view(const float cone[4], const float X[3], const float Y[3], const float Z[3],
+                          const float O[3], const rtf::TriRec *edge, double scene_extent, double reach_max,
+                          SlotView *out)
+{
+    out->planes = false;
+    out->ct = 1.0; out->st = 0.0;
+    out->a[0] = out->a[1] = out->a[2] = 0.0;
+    const float cw = cone[3];
+    if (cw >= 2.0f) { out->cone = 0; return; }
+    out->cone = 2;
+    if (cw > -2.0f) {
+        const double a[3] = {(double)cone[0], (double)cone[1], (double)cone[2]};
+        const double al = sqrt(rtf::dot3d(a, a));
+        if (al > 0.0) {
+            double ct = (double)cw / al - 9.5367431640625e-07; // 2^-20
+            if (ct > -0.5) {              // else: half-angle beyond 2 rad, treated as "every direction"
+                if (ct > 1.0) ct = 1.0;
+                out->cone = 1;
+                out->ct = ct;
+                out->st = sqrt(1.0 - ct * ct);
+                for (int i = 0; i < 3; i++) out->a[i] = a[i] / al;
+            }
+        }
+    }
+    if (!(edge->v[0] == edge->v[0])) return; // NaN record: no ray passes it anyway
+    double p[3][3];
+    for (int i = 0; i < 3; i++) {
+        p[0][i] = (double)X[i] - (double)O[i];
+        p[1][i] = (double)Y[i] - (double)O[i];
+        p[2][i] = (double)Z[i] - (double)O[i];
+    }
+    for (int v = 0; v < 3; v++) {
+        const double l = sqrt(rtf::dot3d(p[v], p[v]));
+        if (!(l > 0.0) || !(l < 1e300)) return;
+    }
+    double e1[3], e2[3], N[3];
+    for (int i = 0; i < 3; i++) { e1[i] = p[1][i] - p[0][i]; e2[i] = p[2][i] - p[0][i]; }
+    rtf::cross3d(e1, e2, N);
+    const double nl = sqrt(rtf::dot3d(N, N));
+    if (!(nl > 0.0)) return;
+    const double h = fabs(rtf::dot3d(p[0], N)) / nl;
+    if (!(h > scene_extent * 1.52587890625e-05)) return; // 2^-16
+    for (int k = 0; k < 3; k++) {
+        const double c[3] = {(double)edge->v[3 * k], (double)edge->v[3 * k + 1], (double)edge->v[3 * k + 2]};
+        const double cl = sqrt(rtf::dot3d(c, c));
+        const double sg = rtf::dot3d(c, p[k]); // sign only: the opposite vertex is inside
+        if (!(cl > 0.0) || !(cl < 1e300) || !(sg != 0.0)) return;
+        const double delta = 3.0517578125e-05 * reach_max * 1.001 + 2.384185791015625e-07 * cl; // 2^-15, 2^-22
+        out->b[k] = -delta / cl;
+        if (!(out->b[k] > -0.5)) return;
+        const double sc = (sg > 0.0 ? 1.0 : -1.0) / cl;
+        for (int i = 0; i < 3; i++) out->n[k][i] = c[i] * sc;
+    }
+    out->planes = true;
+}
+
+// Can a ray of the cell get this slot past its cone test and the edge filter?  The cell may be of
+// any level of the grid (a coarser cell is the union of the four below it).
+//   cone:   a direction of the cell passes only if angle(A, axis) <= th + psi (th + psi < pi here,
+//           where the cosine still decreases);
+//   planes: every direction of the cell is within psi of A, so d . n_k <= A . n_k + psi.
+RT_HD bool cell_meets_slot(const CellCone &cc, const SlotView &v)
+{
+    if (v.cone == 0) return false;
+    if (v.cone == 1 && rtf::dot3d(cc.a, v.a) < v.ct * cc.cpsi - v.st * cc.spsi - 1e-9) return false;
+    if (v.planes)
+        for (int k = 0; k < 3; k++)
+            if (rtf::dot3d(v.n[k], cc.a) + cc.psi + 1e-6 < v.b[k]) return false;
+    return true;
+}
+// a slot that is on the list of every cell
+RT_HD bool slot_everywhere(const SlotView &v) { return v.cone == 2 && !v.planes; }
+
+// The same two tests from the records themselves (the cone hierarchy of the traversal and the
+// host model use these).
 RT_HD bool cell_overlaps(const CellCone &cc, float cx, float cy, float cz, float cw)
 {
     if (cw >= 2.0f) return false;      // nothing passes this record
@@ -133,56 +236,43 @@ RT_HD bool cell_overlaps(const CellCone &cc, float cx, float cy, float cz, float
     if (ct > 1.0) ct = 1.0;
     const double st = sqrt(1.0 - ct * ct);
     const double c = rtf::dot3d(cc.a, a) / al;
-    // th + psi < pi here, where the cosine still decreases
     return c >= ct * cc.cpsi - st * cc.spsi - 1e-9;
 }
-
-// Second, sharper test: the triangle's three edge planes against the cell.  With n_k, b_k as
-// make_cone_rec forms them from the ROUNDED edge record, the edge filter passes a direction d on the
-// triangle's side of the origin only if d . n_k >= b_k for all three edges.  Its other half (all
-// three <= +delta) holds the directions whose line meets the triangle BEHIND the origin; the
-// reference keeps 0 < t (<= tmax) only, and make_cone_rec's rules -- no vertex at O, O farther than
-// 2^-16 extent from the triangle's plane, edge records that are not degenerate -- are what makes the
-// computed t carry the true sign.  Those rules are checked again here, because a triangle seen
-// nearly edge-on has no cone (its grown spherical triangle is a long wedge) and yet perfectly good
-// edge planes: such a slot would otherwise sit in the list of every cell.  Every direction of the
-// cell is within psi of its axis A, so d . n_k <= A . n_k + psi: if that is below b_k for one edge,
-// no ray of the cell gets this slot past the edge filter and the reference's t > 0.
-// Returns true (keep the slot) whenever a rule fails.
 RT_HD bool cell_meets_edges(const CellCone &cc, const float X[3], const float Y[3], const float Z[3],
                             const float O[3], const rtf::TriRec *edge, double scene_extent, double reach_max)
 {
-    if (!(edge->v[0] == edge->v[0])) return true; // NaN record: no ray passes it anyway
-    double p[3][3];
-    for (int i = 0; i < 3; i++) {
-        p[0][i] = (double)X[i] - (double)O[i];
-        p[1][i] = (double)Y[i] - (double)O[i];
-        p[2][i] = (double)Z[i] - (double)O[i];
-    }
-    for (int v = 0; v < 3; v++) {
-        const double l = sqrt(rtf::dot3d(p[v], p[v]));
-        if (!(l > 0.0) || !(l < 1e300)) return true;
-    }
-    double e1[3], e2[3], N[3];
-    for (int i = 0; i < 3; i++) { e1[i] = p[1][i] - p[0][i]; e2[i] = p[2][i] - p[0][i]; }
-    rtf::cross3d(e1, e2, N);
-    const double nl = sqrt(rtf::dot3d(N, N));
-    if (!(nl > 0.0)) return true;
-    const double h = fabs(rtf::dot3d(p[0], N)) / nl;
-    if (!(h > scene_extent * 1.52587890625e-05)) return true; // 2^-16
-    bool outside = false;
-    for (int k = 0; k < 3; k++) {
-        const double c[3] = {(double)edge->v[3 * k], (double)edge->v[3 * k + 1], (double)edge->v[3 * k + 2]};
-        const double cl = sqrt(rtf::dot3d(c, c));
-        const double sg = rtf::dot3d(c, p[k]); // sign only: the opposite vertex is inside
-        if (!(cl > 0.0) || !(cl < 1e300) || !(sg != 0.0)) return true;
-        const double delta = 3.0517578125e-05 * reach_max * 1.001 + 2.384185791015625e-07 * cl; // 2^-15, 2^-22
-        const double b = -delta / cl;
-        if (!(b > -0.5)) return true;
-        const double an = (sg > 0.0 ? 1.0 : -1.0) * rtf::dot3d(c, cc.a) / cl;
-        if (an + cc.psi + 1e-6 < b) outside = true;
-    }
-    return !outside;
+    const float always[4] = {0.0f, 0.0f, 0.0f, -2.0f};
+    SlotView v;
+    make_slot_view(always, X, Y, Z, O, edge, scene_extent, reach_max, &v);
+    return cell_meets_slot(cc, v);
 }
+
+// Direction cells for the band sweep of arbitrary rays (rt_filter.h, "Plane-band test"): can a
+// direction of the cell pass the float test |a . b| < w of a band record (a group's, a subgroup's, or a
+// member's with a = n/theta, w = 1)?  In angles: the directions that pass lie within
+// beta = asin(w/|a| + 2^-19) of the plane across a (2^-19 covers the float dot product and |b| != 1),
+// those of the cell within psi of its axis A, whose own elevation above that plane is
+// asin(|a . A|/|a|): they can meet only if |a . A|/|a| < sin(beta + psi).
+RT_HD bool cell_meets_band(const CellCone &cc, float ax, float ay, float az, float w)
+{
+    if (!(w > 0.0f)) return false;     // |a . b| < w never holds (padding)
+    const double a[3] = {(double)ax, (double)ay, (double)az};
+    const double al = sqrt(rtf::dot3d(a, a));
+    if (!(al > 0.0)) return true;      // every direction is in this band
+    const double sn = (double)w / al + 1.9073486328125e-06; // 2^-19
+    if (!(sn < 1.0)) return true;
+    const double cs = sqrt(1.0 - sn * sn);
+    if (cs * cc.cpsi - sn * cc.spsi <= 0.0) return true; // beta + psi reaches a right angle
+    return fabs(rtf::dot3d(cc.a, a)) / al < sn * cc.cpsi + cs * cc.spsi + 1e-9;
+}
+
+// The band test does not see the sign of a direction: rays are filed under the cell of the direction
+// folded onto the hemisphere z >= 0 (ties: y, then x), and only cells that reach it have lists.
+RT_HD uint32_t oct_cell_folded(float x, float y, float z, int bits)
+{
+    const bool flip = z < 0.0f || (z == 0.0f && (y < 0.0f || (y == 0.0f && x < 0.0f)));
+    return flip ? oct_cell(-x, -y, -z, bits) : oct_cell(x, y, z, bits);
+}
+RT_HD bool cell_reaches_upper_hemisphere(const CellCone &cc) { return cc.a[2] + cc.psi >= 0.0; }
 
 } // namespace rtg

@@ -365,9 +365,8 @@ __global__ __launch_bounds__(BLOCK) void intersect_setup_kernel(RaySoA r, const 
     if (shared == 1) prepare_shared(job, slot, o, d, so.origin, so.center, so.radius, so.reach_max, so.sign);
     if (shared == 2) prepare_general(job, slot, o, d, so.center, so.radius);
     if (keys) {
-        // the band test does not see the sign of the direction: fold onto one hemisphere
-        const float sg = (d.z < 0.0f || (d.z == 0.0f && (d.y < 0.0f || (d.y == 0.0f && d.x < 0.0f)))) ? -1.0f : 1.0f;
-        keys[slot] = direction_key(d.x * sg, d.y * sg, d.z * sg);
+        // the cell under which the band sweep files the ray (rt_grid.h), 10 bits per axis
+        keys[slot] = rtg::oct_cell_folded(d.x, d.y, d.z, 10);
     }
 }
 
@@ -419,6 +418,9 @@ struct TraverseParams {
     const int *grid_entries;      // the lists: slots
     int grid_bits;                // 2^bits cells per axis
     int num_slots;
+    // direction cells of the band sweep (traverse_bandcell_kernel): lists of member records
+    const unsigned int *band_off;
+    const int *band_entries;
     // clustered traversal of arbitrary rays (traverse_cluster_kernel) only
     int sweeps;                 // host side: which instantiation of traverse_cluster_kernel (bit 0 = sweep A, bit 1 = sweep B)
     const float4 *ngroups;      // one (axis, w) per group of triangles with similar normals
@@ -869,52 +871,80 @@ __launch_bounds__(BLOCK) void traverse_kernel(TraverseParams p)
 
 // ---------------------------------------------------------------------------
 // Direction cells (rt_grid.h): the list of every cell of a shared origin.
-// One thread per cell walks the cone hierarchy of the origin -- a cone per SUPER_RUN slots,
-// per RUN slots, per slot -- and keeps the slots whose cone shares a direction with the cell.
-// FILL = false counts (count[cell]), FILL = true writes the slots at off[cell].
+// One thread per slot walks the cells from the coarsest level down (a cell is the union of its four
+// children) and enters the slot in every finest cell that a ray could get it out of: the slot's cone
+// and its three edge planes against the cell's bounding cone.  A slot no test can bound goes on the
+// list "everywhere" (index num_cells), which every ray sweeps.
+// FILL = false counts into count[]; FILL = true writes the slot at off[cell] + cursor[cell]++.
+// The order of a list is whatever order the threads arrive in; results do not depend on it
+// (closest hits merge by a minimum, shadow rays by an or).
 // ---------------------------------------------------------------------------
+// what the list builder needs to know about each slot, once per slot and origin
+__global__ __launch_bounds__(BLOCK) void slot_view_kernel(const float4 *__restrict__ cones, int num_slots,
+                                                          const rtf::TriRec *__restrict__ recs,
+                                                          const int *__restrict__ tri_of,
+                                                          const rt_vertex *__restrict__ verts, float ox, float oy,
+                                                          float oz, double extent, double reach_max,
+                                                          rtg::SlotView *__restrict__ views)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= num_slots) return;
+    const int tri = tri_of[i];
+    const float4 cone = cones[i];
+    rtg::SlotView view;
+    view.cone = 0;
+    view.planes = false;
+    if (tri >= 0 && cone.w < 2.0f) {
+        const float O[3] = {ox, oy, oz};
+        const float cn[4] = {cone.x, cone.y, cone.z, cone.w};
+        const rtf::TriRec er = recs[i];
+        rtg::make_slot_view(cn, verts[3 * tri].pos, verts[3 * tri + 1].pos, verts[3 * tri + 2].pos, O, &er, extent,
+                            reach_max, &view);
+    }
+    views[i] = view;
+}
+
+constexpr int BUILD_TOP_LEVEL = 3; // one thread per (slot or member, cell of this level)
+constexpr int BUILD_TOP_CELLS = 1 << (2 * BUILD_TOP_LEVEL);
+
 template <bool FILL>
-__global__ __launch_bounds__(BLOCK) void grid_build_kernel(const rtg::CellCone *__restrict__ cells, int num_cells,
-                                                           const float4 *__restrict__ cones,
-                                                           const float4 *__restrict__ rcones,
-                                                           const float4 *__restrict__ scones, int num_slots,
-                                                           const rtf::TriRec *__restrict__ recs,
-                                                           const int *__restrict__ tri_of,
-                                                           const rt_vertex *__restrict__ verts, float ox, float oy,
-                                                           float oz, double extent, double reach_max,
+__global__ __launch_bounds__(BLOCK) void grid_build_kernel(const rtg::CellCone *__restrict__ cells, int bits,
+                                                           const rtg::SlotView *__restrict__ views, int num_slots,
                                                            unsigned int *__restrict__ count,
                                                            const unsigned int *__restrict__ off,
                                                            int *__restrict__ entries)
 {
-    const int cell = blockIdx.x * BLOCK + threadIdx.x;
-    if (cell >= num_cells) return;
-    const rtg::CellCone cc = cells[cell];
-    unsigned int n = 0;
-    const unsigned int base = FILL ? off[cell] : 0u;
-    for (int s = 0; s < num_slots / SUPER_RUN; s++) {
-        const float4 sc = scones[s];
-        if (!rtg::cell_overlaps(cc, sc.x, sc.y, sc.z, sc.w)) continue;
-        for (int r = s * (SUPER_RUN / RUN); r < (s + 1) * (SUPER_RUN / RUN); r++) {
-            const float4 rc = rcones[r];
-            if (!rtg::cell_overlaps(cc, rc.x, rc.y, rc.z, rc.w)) continue;
-            for (int i = r * RUN; i < (r + 1) * RUN; i++) {
-                const float4 c = cones[i];
-                if (!rtg::cell_overlaps(cc, c.x, c.y, c.z, c.w)) continue;
-                {
-                    // the triangle's three edge planes against the cell
-                    const int tri = tri_of[i];
-                    const float O[3] = {ox, oy, oz};
-                    const rtf::TriRec er = recs[i];
-                    if (tri >= 0 && !rtg::cell_meets_edges(cc, verts[3 * tri].pos, verts[3 * tri + 1].pos,
-                                                           verts[3 * tri + 2].pos, O, &er, extent, reach_max))
-                        continue;
-                }
-                if (FILL) entries[base + n] = i;
-                n++;
-            }
+    const long long gid = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    // consecutive lanes take consecutive slots against the same top cell: they agree on most tests
+    const int i = (int)(gid % num_slots);
+    const unsigned int top = (unsigned int)(gid / num_slots);
+    if (top >= (unsigned int)BUILD_TOP_CELLS) return;
+    const rtg::SlotView view = views[i];
+    if (view.cone == 0) return;
+    const unsigned int num_cells = 1u << (2 * bits);
+    auto emit = [&](unsigned int cell) {
+        const unsigned int k = atomicAdd(&count[cell], 1u);
+        if (FILL) entries[off[cell] + k] = i;
+    };
+    if (rtg::slot_everywhere(view)) {
+        if (top == 0) emit(num_cells);
+        return;
+    }
+    unsigned int stack[3 * (rtg::MAX_BITS - BUILD_TOP_LEVEL) + 8]; // (level << 24) | cell
+    int sp = 0;
+    stack[sp++] = ((unsigned int)BUILD_TOP_LEVEL << 24) | top;
+    while (sp > 0) {
+        const unsigned int e = stack[--sp];
+        const int level = (int)(e >> 24);
+        const unsigned int cell = e & 0xffffffu;
+        const rtg::CellCone cc = cells[rtg::level_offset(level) + cell];
+        if (!rtg::cell_meets_slot(cc, view)) continue;
+        if (level == bits) {
+            emit(cell);
+        } else {
+            for (unsigned int k = 0; k < 4; k++) stack[sp++] = ((unsigned int)(level + 1) << 24) | (cell * 4 + k);
         }
     }
-    if (!FILL) count[cell] = n;
 }
 
 // ---------------------------------------------------------------------------
@@ -1009,12 +1039,14 @@ __global__ __launch_bounds__(BLOCK) void traverse_grid_kernel(TraverseParams p)
         }
     };
 
-    // the rays in `group` against the slots list[0 .. cnt) (list == nullptr: slots 0 .. cnt)
-    auto sweep = [&](const int *list, int cnt, unsigned long long group) {
-        for (int base = 0; base < cnt && group; base += 64) {
+    // the rays in `group` against the slots list[0 .. cnt) followed by elist[0 .. ecnt)
+    // (list == nullptr: slots 0 .. cnt)
+    auto sweep = [&](const int *list, int cnt, const int *elist, int ecnt, unsigned long long group) {
+        for (int base = 0; base < cnt + ecnt && group; base += 64) {
             const int idx = base + lane;
             int e = -1, tri = -1;
             if (idx < cnt) e = list ? list[idx] : idx;
+            else if (idx < cnt + ecnt) e = elist[idx - cnt];
             float4 r0 = make_float4(qn, qn, qn, qn), r1 = r0, r2 = r0;
             if (e >= 0) {
                 const float4 *rp = reinterpret_cast<const float4 *>(p.recs + e);
@@ -1051,6 +1083,10 @@ __global__ __launch_bounds__(BLOCK) void traverse_grid_kernel(TraverseParams p)
     };
 
     unsigned long long remaining = __builtin_amdgcn_ballot_w64(live && !wild);
+    // the slots that are on every cell's list follow the cell's own
+    const unsigned int every = 1u << (2 * p.grid_bits);
+    const unsigned int eoff = p.grid_off[every];
+    const int ecnt = (int)(p.grid_off[every + 1] - eoff);
     while (remaining) {
         const int leader = __builtin_ctzll(remaining);
         const unsigned int c0 = (unsigned int)__builtin_amdgcn_readlane((int)cell, leader);
@@ -1058,10 +1094,10 @@ __global__ __launch_bounds__(BLOCK) void traverse_grid_kernel(TraverseParams p)
         remaining &= ~group;
         const unsigned int off = p.grid_off[c0];
         const int cnt = (int)(p.grid_off[c0 + 1] - off);
-        sweep(p.grid_entries + off, cnt, group);
+        sweep(p.grid_entries + off, cnt, p.grid_entries + eoff, ecnt, group);
     }
     const unsigned long long wilds = __builtin_amdgcn_ballot_w64(wild);
-    if (wilds) sweep(nullptr, p.num_slots, wilds);
+    if (wilds) sweep(nullptr, p.num_slots, nullptr, 0, wilds);
     drain(true);
 
     if (lane == 0) {
@@ -1544,6 +1580,185 @@ __global__ __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(BLOCK) v
         add_counter(p.counters, C_CH_CAND, n_cand);
         add_counter(p.counters, C_CH_SLOW, n_slow);
     }
+}
+
+// ---------------------------------------------------------------------------
+// Direction cells of the band sweep: for every cell that reaches the hemisphere z >= 0, the member
+// records (positions in nrecs) whose band shares a direction with the cell.  One thread per member
+// walks the cells from the coarsest level down, as grid_build_kernel does.  A member whose band is
+// every direction goes on the list "everywhere" (index num_cells); padding and never-accepted
+// members on none.  FILL as in grid_build_kernel.
+// ---------------------------------------------------------------------------
+template <bool FILL>
+__global__ __launch_bounds__(BLOCK) void band_build_kernel(const rtg::CellCone *__restrict__ cells, int bits,
+                                                           const float4 *__restrict__ nrecs, int num_members,
+                                                           unsigned int *__restrict__ count,
+                                                           const unsigned int *__restrict__ off,
+                                                           int *__restrict__ entries)
+{
+    const long long gid = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    const int pos = (int)(gid % num_members);
+    const unsigned int top = (unsigned int)(gid / num_members);
+    if (top >= (unsigned int)BUILD_TOP_CELLS) return;
+    const float4 m1 = nrecs[2 * pos], m2 = nrecs[2 * pos + 1];
+    if (__float_as_int(m2.w) < 0 || m1.w == 2.0f) return; // padding / never accepted
+    const unsigned int num_cells = 1u << (2 * bits);
+    auto emit = [&](unsigned int cell) {
+        const unsigned int k = atomicAdd(&count[cell], 1u);
+        if (FILL) entries[off[cell] + k] = pos;
+    };
+    if (m1.x == 0.0f && m1.y == 0.0f && m1.z == 0.0f) { // its band is every direction
+        if (top == 0) emit(num_cells);
+        return;
+    }
+    unsigned int stack[3 * (rtg::MAX_BITS - BUILD_TOP_LEVEL) + 8]; // (level << 24) | cell
+    int sp = 0;
+    stack[sp++] = ((unsigned int)BUILD_TOP_LEVEL << 24) | top;
+    while (sp > 0) {
+        const unsigned int e = stack[--sp];
+        const int level = (int)(e >> 24);
+        const unsigned int cell = e & 0xffffffu;
+        const rtg::CellCone cc = cells[rtg::level_offset(level) + cell];
+        if (!rtg::cell_reaches_upper_hemisphere(cc) || !rtg::cell_meets_band(cc, m1.x, m1.y, m1.z, 1.0f)) continue;
+        if (level == bits) {
+            emit(cell);
+        } else {
+            for (unsigned int k = 0; k < 4; k++) stack[sp++] = ((unsigned int)(level + 1) << 24) | (cell * 4 + k);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Band sweep (sweep A of the clustered traversal) over direction cells.  Same pairs reach the general
+// edge filter as in traverse_band_kernel -- the members whose band holds the ray's direction and
+// whose slab holds its origin, every member for a ray outside the records' range -- but each ray
+// meets only the members on the list of its direction's cell.  Structure as traverse_grid_kernel:
+// one ray per lane, wavefronts independent, the cell's list read 64 members at a time, one member per
+// lane, the rays of the cell broadcast in turn.  Survivors are queued and go through the edge filter
+// and the reference arithmetic one pair per lane; results merge into p.best by atomicMin.
+// grid = ray blocks of 256.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void traverse_bandcell_kernel(TraverseParams p)
+{
+    __shared__ unsigned long long best_all[BLOCK];
+    __shared__ float4 ray_o_all[BLOCK], ray_d_all[BLOCK]; // (origin, |g|), (direction, -)
+    __shared__ unsigned int queue_all[(BLOCK / 64) * GRID_QCAP];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = p.count ? *p.count : p.n;
+    const int s = blockIdx.x * BLOCK + tid;
+    if (blockIdx.x * BLOCK + wave * 64 >= n) return; // the whole wavefront; no barriers below
+    unsigned long long *best = best_all + wave * 64;
+    float4 *ray_o = ray_o_all + wave * 64, *ray_d = ray_d_all + wave * 64;
+    unsigned int *queue = queue_all + wave * GRID_QCAP;
+
+    const bool valid = s < n;
+    const int sl = valid ? (p.alist ? p.alist[s] : s) : 0;
+    const float qn = __int_as_float(0x7fc00000);
+    float ox = qn, oy = qn, oz = qn, bx = qn, by = qn, bz = qn, g = qn;
+    unsigned int cell = 0;
+    if (valid) {
+        ox = p.job.ox[sl]; oy = p.job.oy[sl]; oz = p.job.oz[sl];
+        bx = p.job.bx[sl]; by = p.job.by[sl]; bz = p.job.bz[sl];
+        g = p.job.g[sl];
+        cell = rtg::oct_cell_folded(bx, by, bz, p.grid_bits);
+        ray_o[lane] = make_float4(ox, oy, oz, fabsf(g));
+        ray_d[lane] = make_float4(p.job.dx[sl], p.job.dy[sl], p.job.dz[sl], 0.0f);
+    }
+    const bool wild = valid && !(g > 0.0f); // outside the records' range: in every band and slab
+    best[lane] = BEST_NONE;
+
+    int qcount = 0; // wave-uniform
+    unsigned long long n_cand = 0, n_slow = 0;
+
+    // the edge filter and the reference arithmetic for queued (triangle, ray) pairs, one per lane
+    auto drain = [&](bool all) {
+        while (qcount >= 64 || (all && qcount > 0)) {
+            const int take = qcount >= 64 ? 64 : qcount;
+            qcount -= take;
+            if (lane < take) {
+                const unsigned int e = queue[qcount + lane];
+                const int r = (int)(e & 63u);
+                const int tri = (int)(e >> 6);
+                const float4 ro = ray_o[r], rd = ray_d[r];
+                const float gg = ro.w;
+                if (rtf::filter_general(reinterpret_cast<const float *>(p.recs + tri), ro.x, ro.y, ro.z, rd.x * gg,
+                                        rd.y * gg, rd.z * gg) >= -1.0f) {
+                    const v3 o = rtx::V(ro.x, ro.y, ro.z), d = rtx::V(rd.x, rd.y, rd.z);
+                    const v3 X = vpos(p.verts, 3 * tri), Y = vpos(p.verts, 3 * tri + 1), Z = vpos(p.verts, 3 * tri + 2);
+                    float t;
+                    if (rtx::ray_vs_triangle(o, d, X, Y, Z, t) && t > 0.0f) {
+                        const unsigned long long key =
+                            ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)(unsigned int)tri;
+                        atomicMin(&best[r], key);
+                    }
+                }
+            }
+            n_cand += take;
+        }
+    };
+
+    // the rays in `group` against the members list[0 .. cnt) (list == nullptr: positions 0 .. cnt,
+    // every one of them a candidate: rays outside the records' range)
+    auto sweep = [&](const int *list, int cnt, const int *elist, int ecnt, unsigned long long group) {
+        for (int base = 0; base < cnt + ecnt; base += 64) {
+            const int idx = base + lane;
+            float4 m1 = make_float4(0.0f, 0.0f, 0.0f, 2.0f), m2 = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
+            if (idx < cnt + ecnt) {
+                const int pos = idx < cnt ? (list ? list[idx] : idx) : elist[idx - cnt];
+                m1 = p.nrecs[2 * pos];
+                m2 = p.nrecs[2 * pos + 1];
+            }
+            const int tri = __float_as_int(m2.w);
+            const bool member = tri >= 0 && m1.w != 2.0f; // not padding, not "never accepted"
+            unsigned long long m = group;
+            while (m) {
+                const int r = __builtin_ctzll(m);
+                m &= m - 1;
+                bool in = member;
+                if (list) {
+                    const float rbx = readlane_f(bx, r), rby = readlane_f(by, r), rbz = readlane_f(bz, r);
+                    const float rox = readlane_f(ox, r), roy = readlane_f(oy, r), roz = readlane_f(oz, r);
+                    const float t0 = fmaf(m1.z, rbz, fmaf(m1.y, rby, m1.x * rbx));
+                    const float h0 = fmaf(m2.z, roz, fmaf(m2.y, roy, fmaf(m2.x, rox, -m1.w)));
+                    in = in && fmaxf(fabsf(t0), fabsf(h0)) < 1.0f;
+                }
+                const unsigned long long h = __builtin_amdgcn_ballot_w64(in);
+                if (h) {
+                    if (in) queue[qcount + lanes_below(h)] = ((unsigned int)tri << 6) | (unsigned int)r;
+                    qcount += __popcll(h);
+                    if (qcount > GRID_QCAP - 64) drain(false);
+                }
+            }
+            n_slow += __popcll(group);
+        }
+    };
+
+    unsigned long long remaining = __builtin_amdgcn_ballot_w64(valid && !wild);
+    // the members that are on every cell's list follow the cell's own
+    const unsigned int every = 1u << (2 * p.grid_bits);
+    const unsigned int eoff = p.band_off[every];
+    const int ecnt = (int)(p.band_off[every + 1] - eoff);
+    while (remaining) {
+        const int leader = __builtin_ctzll(remaining);
+        const unsigned int c0 = (unsigned int)__builtin_amdgcn_readlane((int)cell, leader);
+        const unsigned long long group = __builtin_amdgcn_ballot_w64(cell == c0) & remaining;
+        remaining &= ~group;
+        const unsigned int off = p.band_off[c0];
+        const int cnt = (int)(p.band_off[c0 + 1] - off);
+        sweep(p.band_entries + off, cnt, p.band_entries + eoff, ecnt, group);
+    }
+    const unsigned long long wilds = __builtin_amdgcn_ballot_w64(wild);
+    if (wilds) sweep(nullptr, p.num_ngroups * NGROUP, nullptr, 0, wilds);
+    drain(true);
+
+    if (lane == 0) {
+        add_counter(p.counters, C_CH_CAND, n_cand);
+        add_counter(p.counters, C_CH_SLOW, n_slow);
+    }
+    if (!valid) return;
+    const unsigned long long key = best[lane];
+    if (key != BEST_NONE) atomicMin(&p.best[sl], key);
 }
 
 // ---------------------------------------------------------------------------

@@ -275,13 +275,12 @@ extern "C" void fm_check_cluster_cone(int n_tris, const float *verts, int n_rays
 
 // ---------------------------------------------------------------------------------------------
 // Direction cells (rt_grid.h), as grid_build_kernel + traverse_grid_kernel evaluate them: a pair
-// reaches the reference arithmetic iff the triangle is on the list of the ray's cell -- its cone
-// record and its three edge planes both meet the cell, and so do the cones of its run of 16 and of
-// the four runs above it -- or the ray is outside the cones' validity (wild), AND the edge filter
-// passes.  The triangles are taken in the given order, 16 per run, 64 per cone of the level above.
+// reaches the reference arithmetic iff the slot is on the list of the ray's cell -- its cone record
+// and its three edge planes meet the cell and every coarser cell above it -- or on the list
+// "everywhere", or the ray is outside the cones' validity (wild), AND the edge filter passes.
 // stats: [0] pairs [1] pairs on the cell's list [2] pairs reaching the reference arithmetic
 //        [3] oracle accepts [4] violations [5] pairs the cone + edge filter cascade lets through
-//        [6] wild rays [7] listed pairs whose run or upper cone misses the cell (must be 0)
+//        [6] wild rays [7] pairs where the record-based tests and the slot view disagree (must be 0)
 // ---------------------------------------------------------------------------------------------
 #include "../../opengl_raytracer_amd/csrc/rt_grid.h"
 
@@ -292,19 +291,9 @@ extern "C" void fm_check_grid(int n_tris, const float *verts, int n_rays, const 
     const double extent = rtf::scene_extent(O, center, radius);
     const double rmax = rtf::cone_reach_max(O, center, radius);
     const float rmaxf = (float)rmax;
-    const int runs = (n_tris + 15) / 16, supers = (runs + 3) / 4;
-    std::vector<rtf::TriRec> recs((size_t)supers * 64);
-    std::vector<rtf::ConeRec> cones((size_t)supers * 64), rc((size_t)supers * 4), sc(supers);
-    for (int k = 0; k < supers * 64; k++) {
-        if (k >= n_tris) { rtf::nan_rec(&recs[k]); rtf::cone_never(&cones[k]); continue; }
-        const float *X = verts + 9 * k, *Y = X + 3, *Z = X + 6;
-        rtf::make_origin_rec(X, Y, Z, O, &recs[k]);
-        rtf::make_cone_rec(X, Y, Z, O, &recs[k], extent, rmax, &cones[k]);
-    }
-    for (int r = 0; r < supers * 4; r++) rtf::make_cluster_cone(&cones[(size_t)r * 16], 16, &rc[r]);
-    for (int q = 0; q < supers; q++) rtf::make_cluster_cone(&rc[(size_t)q * 4], 4, &sc[q]);
-    // per ray: unit direction, scale, cell cone
-    std::vector<rtg::CellCone> cc(n_rays);
+    const int levels = bits - rtg::MIN_LEVEL + 1;
+    // per ray: unit direction, scale, the cones of its cell at every level
+    std::vector<rtg::CellCone> cc((size_t)n_rays * levels);
     std::vector<float> bb((size_t)n_rays * 4);
     std::vector<char> wild(n_rays);
     long long wildn = 0;
@@ -317,25 +306,34 @@ extern "C" void fm_check_grid(int n_tris, const float *verts, int n_rays, const 
         bb[4 * i + 3] = rtf::dir_scale(reach, bx, by, bz);
         wild[i] = !(reach <= rmaxf);
         wildn += wild[i];
-        rtg::make_cell_cone(rtg::oct_cell(bx, by, bz, bits), bits, &cc[i]);
+        const uint32_t cell = rtg::oct_cell(bx, by, bz, bits);
+        for (int l = rtg::MIN_LEVEL; l <= bits; l++)
+            rtg::make_cell_cone(cell >> (2 * (bits - l)), l, &cc[(size_t)i * levels + (l - rtg::MIN_LEVEL)]);
     }
-    long long pairs = 0, listed_n = 0, p2 = 0, acc = 0, bad = 0, old_n = 0, hier = 0;
-#pragma omp parallel for reduction(+ : pairs, listed_n, p2, acc, bad, old_n, hier) schedule(static)
+    long long pairs = 0, listed_n = 0, p2 = 0, acc = 0, bad = 0, old_n = 0, differ = 0;
+#pragma omp parallel for reduction(+ : pairs, listed_n, p2, acc, bad, old_n, differ) schedule(static)
     for (int k = 0; k < n_tris; k++) {
         const float *X = verts + 9 * k, *Y = X + 3, *Z = X + 6;
-        const rtf::ConeRec &cone = cones[k], &rcone = rc[k / 16], &scone = sc[k / 64];
+        rtf::TriRec rec;
+        rtf::ConeRec cone;
+        rtf::make_origin_rec(X, Y, Z, O, &rec);
+        rtf::make_cone_rec(X, Y, Z, O, &rec, extent, rmax, &cone);
+        rtg::SlotView view;
+        rtg::make_slot_view(cone.v, X, Y, Z, O, &rec, extent, rmax, &view);
         for (int i = 0; i < n_rays; i++) {
             const float *o = org + 3 * i, *d = dir + 3 * i;
             const float bx = bb[4 * i], by = bb[4 * i + 1], bz = bb[4 * i + 2], g = fabsf(bb[4 * i + 3]);
-            bool listed = rtg::cell_overlaps(cc[i], cone.v[0], cone.v[1], cone.v[2], cone.v[3]) &&
-                          rtg::cell_meets_edges(cc[i], X, Y, Z, O, &recs[k], extent, rmax);
-            if (listed) {
-                const bool up = rtg::cell_overlaps(cc[i], rcone.v[0], rcone.v[1], rcone.v[2], rcone.v[3]) &&
-                                rtg::cell_overlaps(cc[i], scone.v[0], scone.v[1], scone.v[2], scone.v[3]);
-                hier += !up;
-                listed = up; // the build never reaches a slot whose run it has skipped
+            const rtg::CellCone *chain = &cc[(size_t)i * levels];
+            bool listed = view.cone != 0;
+            if (listed && !rtg::slot_everywhere(view))
+                for (int l = 0; l < levels && listed; l++) listed = rtg::cell_meets_slot(chain[l], view);
+            {
+                const rtg::CellCone &leaf = chain[levels - 1];
+                const bool by_records = rtg::cell_overlaps(leaf, cone.v[0], cone.v[1], cone.v[2], cone.v[3]) &&
+                                        rtg::cell_meets_edges(leaf, X, Y, Z, O, &rec, extent, rmax);
+                differ += by_records != rtg::cell_meets_slot(leaf, view);
             }
-            const bool edge = rtf::filter_origin(recs[k].v, bx * g, by * g, bz * g) >= -1.0f;
+            const bool edge = rtf::filter_origin(rec.v, bx * g, by * g, bz * g) >= -1.0f;
             const bool reach_exact = (listed || wild[i]) && edge;
             const float dt = fmaf(cone.v[2], bz, fmaf(cone.v[1], by, cone.v[0] * bx));
             const bool old_path = ((dt >= cone.v[3]) || wild[i]) && edge;
@@ -351,5 +349,64 @@ extern "C" void fm_check_grid(int n_tris, const float *verts, int n_rays, const 
         }
     }
     stats[0] = pairs; stats[1] = listed_n; stats[2] = p2; stats[3] = acc; stats[4] = bad; stats[5] = old_n;
-    stats[6] = wildn; stats[7] = hier;
+    stats[6] = wildn; stats[7] = differ;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Direction cells of the band sweep, as band_build_kernel + traverse_bandcell_kernel evaluate them:
+// a member is on the list of the ray's (folded) cell iff its band meets the cell and every coarser
+// cell above it, all of which reach the hemisphere z >= 0; members whose band is every direction are
+// on the list "everywhere".  A pair the member test  max(|n1.b|, |n2.o - kappa'|) < 1  lets through
+// must be listed.
+// stats: [0] pairs [1] listed [2] member test passes [3] violations (passes && !listed)
+// ---------------------------------------------------------------------------------------------
+extern "C" void fm_check_band_cells(int n_tris, const float *verts, int n_rays, const float *org, const float *dir,
+                                    const float *center, float radius, int bits, long long *stats)
+{
+    rtc::ClusterSet cs;
+    std::vector<rt_vertex> v((size_t)n_tris * 3);
+    for (int i = 0; i < n_tris * 3; i++) {
+        memset(&v[i], 0, sizeof(rt_vertex));
+        for (int a = 0; a < 3; a++) v[i].pos[a] = verts[3 * i + a];
+    }
+    rtc::build(v.data(), n_tris, center, radius, cs);
+    const int levels = bits - rtg::MIN_LEVEL + 1;
+    std::vector<rtg::CellCone> cc((size_t)n_rays * levels);
+    std::vector<float> bb((size_t)n_rays * 3);
+    for (int i = 0; i < n_rays; i++) {
+        const float *d = dir + 3 * i;
+        const float inv = 1.0f / sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        bb[3 * i] = d[0] * inv; bb[3 * i + 1] = d[1] * inv; bb[3 * i + 2] = d[2] * inv;
+        const uint32_t cell = rtg::oct_cell_folded(bb[3 * i], bb[3 * i + 1], bb[3 * i + 2], bits);
+        for (int l = rtg::MIN_LEVEL; l <= bits; l++)
+            rtg::make_cell_cone(cell >> (2 * (bits - l)), l, &cc[(size_t)i * levels + (l - rtg::MIN_LEVEL)]);
+    }
+    const size_t members = cs.nmembers.size();
+    long long pairs = 0, listed_n = 0, pass_n = 0, bad = 0;
+#pragma omp parallel for reduction(+ : pairs, listed_n, pass_n, bad) schedule(static)
+    for (size_t pos = 0; pos < members; pos++) {
+        const float *m1 = &cs.nrecs[pos * 8], *m2 = m1 + 4;
+        int32_t tri;
+        memcpy(&tri, &m2[3], 4);
+        if (tri < 0 || m1[3] == 2.0f) continue;
+        const bool everywhere = m1[0] == 0.0f && m1[1] == 0.0f && m1[2] == 0.0f;
+        for (int i = 0; i < n_rays; i++) {
+            const float *o = org + 3 * i;
+            const float bx = bb[3 * i], by = bb[3 * i + 1], bz = bb[3 * i + 2];
+            bool listed = true;
+            if (!everywhere)
+                for (int l = 0; l < levels && listed; l++) {
+                    const rtg::CellCone &c = cc[(size_t)i * levels + l];
+                    listed = rtg::cell_reaches_upper_hemisphere(c) && rtg::cell_meets_band(c, m1[0], m1[1], m1[2], 1.0f);
+                }
+            const float t0 = fmaf(m1[2], bz, fmaf(m1[1], by, m1[0] * bx));
+            const float h0 = fmaf(m2[2], o[2], fmaf(m2[1], o[1], fmaf(m2[0], o[0], -m1[3])));
+            const bool pass = fmaxf(fabsf(t0), fabsf(h0)) < 1.0f;
+            pairs++;
+            listed_n += listed;
+            pass_n += pass;
+            bad += (pass && !listed);
+        }
+    }
+    stats[0] = pairs; stats[1] = listed_n; stats[2] = pass_n; stats[3] = bad;
 }

@@ -535,7 +535,7 @@ def run_grid(fm, tris, O, org, dirs, sign, tmax=None, bits=8):
                                  C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_void_p]
     fm.fm_check_grid(tris.shape[0], tris.ctypes.data, org.shape[0], O.ctypes.data, org.ctypes.data,
                      dirs.ctypes.data, tm.ctypes.data if tm is not None else None, c.ctypes.data, r, sign, bits, stats)
-    return dict(zip(["pairs", "listed", "both", "accepts", "bad", "cascade", "wild", "hier"], list(stats)))
+    return dict(zip(["pairs", "listed", "both", "accepts", "bad", "cascade", "wild", "differ"], list(stats)))
 
 
 def shadow_rays_towards(rs, tris, L, extent, per_tri=6, far=None):
@@ -562,7 +562,7 @@ def test_direction_cells_primary_rays(fm, sc, bits):
         _, dirs = rays_through_features(rs, tris, O[None, :].astype(np.float64))
         org = (O[None, :] + dirs * f32(0.001)).astype(f32)
         st = run_grid(fm, tris, O, org, dirs, 1.0, bits=bits)
-        assert st["bad"] == 0 and st["hier"] == 0, st
+        assert st["bad"] == 0 and st["differ"] == 0, st
         assert st["accepts"] > 1000 and st["wild"] == 0, st
         if sc["name"] == "soup" and bits >= 8:
             # the lists are short: far fewer pairs than the cone test alone lets through to the edge filter
@@ -600,7 +600,7 @@ def test_direction_cells_rays_on_cell_borders_and_octahedron_seams(fm):
     org = (O[None, :] + d * f32(0.001)).astype(f32)
     for bits in (8, 9):
         st = run_grid(fm, tris, O, org, d, 1.0, bits=bits)
-        assert st["bad"] == 0 and st["hier"] == 0, st
+        assert st["bad"] == 0 and st["differ"] == 0, st
         assert st["accepts"] > 1000, st
 
 
@@ -619,7 +619,7 @@ def test_direction_cells_nasty_triangles_and_origins_on_planes(fm):
         dirs = dirs[fin]
         org = (origin[None, :] + dirs * f32(0.001)).astype(f32)
         st = run_grid(fm, tris, origin, org, dirs, 1.0)
-        assert st["bad"] == 0 and st["hier"] == 0 and st["accepts"] > 1000, st
+        assert st["bad"] == 0 and st["differ"] == 0 and st["accepts"] > 1000, st
 
 
 def test_direction_cells_edge_on_slivers_leave_the_lists(fm):
@@ -642,7 +642,7 @@ def test_direction_cells_edge_on_slivers_leave_the_lists(fm):
     _, dirs = rays_through_features(rs, tris, O[None, :].astype(np.float64))
     org = (O[None, :] + dirs * f32(0.001)).astype(f32)
     st = run_grid(fm, tris, O, org, dirs, 1.0)
-    assert st["bad"] == 0 and st["hier"] == 0 and st["accepts"] > 200, st
+    assert st["bad"] == 0 and st["differ"] == 0 and st["accepts"] > 200, st
     # every ray here is aimed at one of the slivers, whose wedges are long; without the plane test all pairs are listed
     assert st["listed"] < 0.3 * st["pairs"], st
 
@@ -654,7 +654,7 @@ def test_direction_cells_shadow_rays(fm, sc):
     L = (rs.uniform(-3, 3, 3) * sc["extent"] + np.asarray(sc["offset"])).astype(f32)
     org, ld, tmax = shadow_rays_towards(rs, tris, L, sc["extent"])
     st = run_grid(fm, tris, L, org, ld, -1.0, tmax)
-    assert st["bad"] == 0 and st["hier"] == 0, st
+    assert st["bad"] == 0 and st["differ"] == 0, st
     assert st["accepts"] > 300, st
 
 
@@ -671,8 +671,60 @@ def test_direction_cells_light_near_surfaces_and_wild_rays(fm):
                                        c[0] * a + c[1] * b - 0.3 * rs.normal() * (a + b)])).astype(f32)
     org, ld, tmax = shadow_rays_towards(rs, tris, L, 1.0)
     st = run_grid(fm, tris, L, org, ld, -1.0, tmax)
-    assert st["bad"] == 0 and st["hier"] == 0, st
+    assert st["bad"] == 0 and st["differ"] == 0, st
     # rays that start far outside the scene bound meet every slot
     org, ld, _ = shadow_rays_towards(rs, tris, L, 1.0, per_tri=2, far=500.0)
     st = run_grid(fm, tris, L, org, ld, -1.0, np.full(ld.shape[0], 1e9, dtype=f32))
     assert st["bad"] == 0 and st["wild"] == ld.shape[0], st
+
+
+def run_band_cells(fm, tris, org, dirs, bits=8):
+    c, r = bounding_sphere(tris)
+    stats = (C.c_longlong * 4)()
+    tris = np.ascontiguousarray(tris, dtype=f32)
+    org = np.ascontiguousarray(org, dtype=f32)
+    dirs = np.ascontiguousarray(dirs, dtype=f32)
+    fm.fm_check_band_cells.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
+                                       C.c_int, C.c_void_p]
+    fm.fm_check_band_cells(tris.shape[0], tris.ctypes.data, org.shape[0], org.ctypes.data, dirs.ctypes.data,
+                           c.ctypes.data, r, bits, stats)
+    return dict(zip(["pairs", "listed", "passes", "bad"], list(stats)))
+
+
+def in_plane_rays(rs, tris, n_per=4, tilt=(-9, -4)):
+    """Rays that start in (or a hair off) a triangle's plane and run along it (or a hair out of it)."""
+    t = tris.astype(np.float64)
+    e1, e2 = t[:, 1] - t[:, 0], t[:, 2] - t[:, 0]
+    nrm = np.cross(e1, e2)
+    ok = np.linalg.norm(nrm, axis=1) > 1e-12
+    t, e1, e2, nrm = t[ok], e1[ok], e2[ok], nrm[ok]
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    orgs, dirs = [], []
+    for _ in range(n_per):
+        a, b = rs.uniform(-3, 3, (2, t.shape[0], 1))
+        o = t[:, 0] + a * e1 + b * e2 + nrm * rs.normal(size=(t.shape[0], 1)) * 10.0 ** rs.uniform(-9, -5, (t.shape[0], 1))
+        a, b = rs.normal(size=(2, t.shape[0], 1))
+        d = a * e1 + b * e2
+        d /= np.linalg.norm(d, axis=1, keepdims=True) + 1e-300
+        d += nrm * rs.normal(size=(t.shape[0], 1)) * 10.0 ** rs.uniform(*tilt, (t.shape[0], 1))
+        orgs.append(o); dirs.append(d)
+    return np.concatenate(orgs).astype(f32), np.concatenate(dirs).astype(f32)
+
+
+@pytest.mark.parametrize("bits", [4, 8, 9])
+def test_band_cells_hold_every_member_a_ray_is_inside(fm, bits):
+    rs = np.random.RandomState(97)
+    tris = np.concatenate([tris_random(rs, 1200, 1.0, 0.05), tris_nasty(rs, 300, 1.0)])
+    org, dirs = in_plane_rays(rs, tris)
+    keep = (np.abs(org).max(1) < 1.2) & np.isfinite(dirs).all(1)     # inside the records' range
+    _, aimed = rays_through_features(rs, tris, org[:50].astype(np.float64), per_tri=1)
+    org = np.concatenate([org[keep], org[keep][:aimed.shape[0]]])
+    dirs = np.concatenate([dirs[keep], aimed[:org.shape[0] - keep.sum()]])
+    # axis-parallel and seam directions too
+    axes = np.concatenate([np.eye(3), -np.eye(3), [[1, 1, 0], [1, -1, 0], [0, 1, 1], [1, 0, -1]]]).astype(f32)
+    org = np.concatenate([org, org[:axes.shape[0]]]); dirs = np.concatenate([dirs, axes])
+    st = run_band_cells(fm, tris, org, dirs, bits=bits)
+    assert st["bad"] == 0, st
+    assert st["passes"] > 1000, st
+    if bits >= 8:
+        assert st["listed"] < 0.5 * st["pairs"], st   # the slivers among the nasty triangles are in every band

@@ -18,6 +18,8 @@ for p in range(wl["passes"]):
         getattr(g, stage)()
         ms = g.stage_ms(); c = g.counters(); log = g.kernel_log()
         kms = float(log["ms"].sum())
+        if os.environ.get("RT_DIAG_LAUNCHES"):
+            print("      launches:", [(int(r["form"]), int(r["rays_per_lane"]), round(float(r["ms"]), 3)) for r in log])
         if stage == "intersect":
             print(f"pass {p} intersect: {ms[1]:8.2f} ms (traverse {kms:8.2f})  rays {c['closest_rays']:9d}  pairs {c['closest_pairs']:.3e}"
                   f"  rate {c['closest_pairs']/max(kms,1e-9)/1e9:7.2f} Tpairs/s  slow steps {c['closest_slow_steps']:.3e}  cand {c['closest_candidates']:.3e}")
