@@ -743,6 +743,8 @@ static int pick_tiles_per_y(int ray_blocks, int tiles)
     return (tiles + want_y - 1) / want_y;
 }
 
+static int pick_rays_per_wave(int n);
+
 static int klog_begin(rt_ctx *c, int stage, int form, int k, bool exact, unsigned long long rays,
                       unsigned long long pairs, size_t *slot)
 {
@@ -828,7 +830,9 @@ static int launch_traverse_clustered(rt_ctx *c, TraverseParams p, int n_upper, b
         if (int r = klog_begin(c, 1, 2, 1, false, (unsigned long long)n_upper,
                                (unsigned long long)n_upper * (unsigned long long)(p.tri_end - p.tri_begin), &ks))
             return r;
-        hipLaunchKernelGGL(traverse_bandcell_kernel, dim3(cdiv(n_upper, BLOCK)), dim3(BLOCK), 0, c->stream, a);
+        a.rays_per_wave = pick_rays_per_wave(n_upper);
+        hipLaunchKernelGGL(traverse_bandcell_kernel, dim3(cdiv(n_upper, (BLOCK / 64) * a.rays_per_wave)), dim3(BLOCK), 0,
+                           c->stream, a);
         HIPCHK(c, hipGetLastError());
         if (int r = klog_end(c, ks)) return r;
         p.sweeps = 2;
@@ -937,6 +941,18 @@ static int build_grid(rt_ctx *c, int which, const rtf::ConeRec *cones, const rtf
     return RT_OK;
 }
 
+// Rays per wavefront of the direction-cell kernels: enough wavefronts to hide the list reads of each
+// (RT_RAYS_PER_WAVE overrides: 1..64).
+static int pick_rays_per_wave(int n)
+{
+    static const int forced = getenv("RT_RAYS_PER_WAVE") ? atoi(getenv("RT_RAYS_PER_WAVE")) : 0;
+    if (forced >= 1 && forced <= 64) return forced;
+    if (n >= 1 << 20) return 64;
+    if (n >= 1 << 18) return 32;
+    if (n >= 1 << 16) return 16;
+    return 8;
+}
+
 // One launch of the direction-cell traversal over the rays of a list.  stage: 1 closest hit, 2 shadow.
 static int launch_traverse_grid(rt_ctx *c, TraverseParams p, int n_upper, int which, bool anyhit, int stage)
 {
@@ -949,8 +965,10 @@ static int launch_traverse_grid(rt_ctx *c, TraverseParams p, int n_upper, int wh
     if (int r = klog_begin(c, stage, 3, 1, false, (unsigned long long)n_upper,
                            (unsigned long long)n_upper * (unsigned long long)c->num_tris, &ks))
         return r;
-    if (anyhit) hipLaunchKernelGGL((traverse_grid_kernel<true>), dim3(cdiv(n_upper, BLOCK)), dim3(BLOCK), 0, c->stream, p);
-    else hipLaunchKernelGGL((traverse_grid_kernel<false>), dim3(cdiv(n_upper, BLOCK)), dim3(BLOCK), 0, c->stream, p);
+    p.rays_per_wave = pick_rays_per_wave(n_upper);
+    const dim3 grid(cdiv(n_upper, (BLOCK / 64) * p.rays_per_wave));
+    if (anyhit) hipLaunchKernelGGL((traverse_grid_kernel<true>), grid, dim3(BLOCK), 0, c->stream, p);
+    else hipLaunchKernelGGL((traverse_grid_kernel<false>), grid, dim3(BLOCK), 0, c->stream, p);
     HIPCHK(c, hipGetLastError());
     return klog_end(c, ks);
 }

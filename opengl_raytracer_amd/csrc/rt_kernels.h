@@ -421,6 +421,7 @@ struct TraverseParams {
     // direction cells of the band sweep (traverse_bandcell_kernel): lists of member records
     const unsigned int *band_off;
     const int *band_entries;
+    int rays_per_wave;            // direction-cell kernels: 64, or fewer for small launches (see their comments)
     // clustered traversal of arbitrary rays (traverse_cluster_kernel) only
     int sweeps;                 // host side: which instantiation of traverse_cluster_kernel (bit 0 = sweep A, bit 1 = sweep B)
     const float4 *ngroups;      // one (axis, w) per group of triangles with similar normals
@@ -959,7 +960,10 @@ __global__ __launch_bounds__(BLOCK) void grid_build_kernel(const rtg::CellCone *
 //                 then into p.best -- the same rule as traverse_kernel.
 //   ANYHIT true : shadow query; sets p.occ.  Rays found occluded leave their cell's loop.
 // Rays outside the range the cones were built for ("wild": job.g < 0) meet every slot.
-// grid = ray blocks of 256.
+// A wavefront takes p.rays_per_wave rays (lanes beyond that hold no ray but still hold slots).  64
+// shares each list read among the most rays; a wavefront walks its lists one read after the other,
+// though, so a small launch is given fewer rays per wavefront and more wavefronts to hide the reads.
+// grid = blocks of 4 wavefronts.
 // ---------------------------------------------------------------------------
 constexpr int GRID_QCAP = 320; // queue entries per wavefront; draining starts when fewer than 64 are free
 
@@ -974,14 +978,16 @@ __global__ __launch_bounds__(BLOCK) void traverse_grid_kernel(TraverseParams p)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = p.count ? *p.count : p.n;
-    const int s = blockIdx.x * BLOCK + tid;
-    if (blockIdx.x * BLOCK + wave * 64 >= n) return; // the whole wavefront; no barriers below
+    const int R = p.rays_per_wave;
+    const int s0 = (blockIdx.x * (BLOCK / 64) + wave) * R;
+    const int s = s0 + lane;
+    if (s0 >= n) return; // the whole wavefront; no barriers below
     unsigned long long *best = best_all + (ANYHIT ? 0 : wave * 64);
     int *occl = occ_all + (ANYHIT ? wave * 64 : 0);
     float4 *ray_o = ray_o_all + wave * 64, *ray_d = ray_d_all + wave * 64;
     unsigned int *queue = queue_all + wave * GRID_QCAP;
 
-    bool valid = s < n;
+    bool valid = lane < R && s < n;
     const int sl = valid ? (p.alist ? p.alist[s] : s) : 0;
     const float qn = __int_as_float(0x7fc00000);
     float hx = qn, hy = qn, hz = qn, g = qn;
@@ -1103,11 +1109,8 @@ __global__ __launch_bounds__(BLOCK) void traverse_grid_kernel(TraverseParams p)
     if (lane == 0) {
         add_counter(p.counters, ANYHIT ? C_SH_CAND : C_CH_CAND, n_cand);
         add_counter(p.counters, ANYHIT ? C_SH_SLOW : C_CH_SLOW, n_slow);
-        if (wave == 0) {
-            const int mine = min(BLOCK, n - blockIdx.x * BLOCK);
-            add_counter(p.counters, ANYHIT ? C_SH_PAIRS : C_CH_PAIRS,
-                        (unsigned long long)mine * (unsigned long long)p.num_tris);
-        }
+        add_counter(p.counters, ANYHIT ? C_SH_PAIRS : C_CH_PAIRS,
+                    (unsigned long long)min(R, n - s0) * (unsigned long long)p.num_tris);
     }
     if (!valid) return;
     if (ANYHIT) {
@@ -1646,13 +1649,15 @@ __global__ __launch_bounds__(BLOCK) void traverse_bandcell_kernel(TraverseParams
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = p.count ? *p.count : p.n;
-    const int s = blockIdx.x * BLOCK + tid;
-    if (blockIdx.x * BLOCK + wave * 64 >= n) return; // the whole wavefront; no barriers below
+    const int R = p.rays_per_wave;
+    const int s0 = (blockIdx.x * (BLOCK / 64) + wave) * R;
+    const int s = s0 + lane;
+    if (s0 >= n) return; // the whole wavefront; no barriers below
     unsigned long long *best = best_all + wave * 64;
     float4 *ray_o = ray_o_all + wave * 64, *ray_d = ray_d_all + wave * 64;
     unsigned int *queue = queue_all + wave * GRID_QCAP;
 
-    const bool valid = s < n;
+    const bool valid = lane < R && s < n;
     const int sl = valid ? (p.alist ? p.alist[s] : s) : 0;
     const float qn = __int_as_float(0x7fc00000);
     float ox = qn, oy = qn, oz = qn, bx = qn, by = qn, bz = qn, g = qn;

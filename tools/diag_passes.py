@@ -9,6 +9,8 @@ name = sys.argv[1] if len(sys.argv) > 1 else "soup64k_4k_p6"
 wl = workload(name)
 g = rt.RayTracer(wl["width"], wl["height"])
 setup_scene(g, wl)
+if os.environ.get("RT_DIAG_WORLD"):  # one rank's share of the frame (interleaved tiles of 16 rows)
+    g.set_row_tiles(16, 0, int(os.environ["RT_DIAG_WORLD"]))
 if os.environ.get('RT_TRACE_MODE'):
     g.set_trace_mode(int(os.environ['RT_TRACE_MODE']))
 g.render(wl["passes"]); g.sync(); g.counters(); g.stage_ms(); g.kernel_log()
