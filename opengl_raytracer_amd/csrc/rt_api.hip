@@ -1034,6 +1034,9 @@ static bool use_grid(const rt_ctx *c)
     return c->grid_bits > 0 && c->trace_mode == RT_TRACE_CLUSTERED && c->num_slots > 0;
 }
 
+// sort keys are direction cells: those of the lists when there are lists, else 10 bits per axis
+static int sort_key_bits(const rt_ctx *c) { return 2 * (c->grid_bits ? c->grid_bits : 10); }
+
 static SharedOrigin shared_origin(rt_ctx *c, const float origin[3], float sign)
 {
     SharedOrigin so{};
@@ -1042,6 +1045,7 @@ static SharedOrigin shared_origin(rt_ctx *c, const float origin[3], float sign)
     so.radius = c->radius;
     so.reach_max = (float)rtf::cone_reach_max(origin, c->center, c->radius);
     so.sign = sign;
+    so.key_bits = sort_key_bits(c) / 2;
     return so;
 }
 
@@ -1093,7 +1097,7 @@ extern "C" int rt_intersect(rt_ctx *c)
             if (sorted) {
                 size_t bytes = c->sort_temp_bytes;
                 HIPCHK(c, rocprim::radix_sort_pairs(c->sort_temp, bytes, c->sort_keys, c->sort_keys_out, c->sort_iota,
-                                                    c->sort_slots, (size_t)n_upper, 0, 20, c->stream));
+                                                    c->sort_slots, (size_t)n_upper, 0, sort_key_bits(c), c->stream));
             }
             TraverseParams p{};
             fill_traverse_common(c, p);
@@ -1186,7 +1190,7 @@ extern "C" int rt_color(rt_ctx *c)
                     if (sorted) {
                         size_t bytes = c->sort_temp_bytes;
                         HIPCHK(c, rocprim::radix_sort_pairs(c->sort_temp, bytes, c->sort_keys, c->sort_keys_out,
-                                                            c->sort_iota, c->sort_slots, (size_t)n0, 0, 20, c->stream));
+                                                            c->sort_iota, c->sort_slots, (size_t)n0, 0, sort_key_bits(c), c->stream));
                         alist = c->sort_slots;
                     }
                     const int *acount = cnt0;

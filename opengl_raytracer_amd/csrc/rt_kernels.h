@@ -321,6 +321,7 @@ struct SharedOrigin { // the shared origin of a launch and the validity range of
     float radius;
     float reach_max;
     float sign;
+    int key_bits; // sort keys: the ray's direction cell with this many bits per axis
 };
 
 struct Scratch {
@@ -365,8 +366,8 @@ __global__ __launch_bounds__(BLOCK) void intersect_setup_kernel(RaySoA r, const 
     if (shared == 1) prepare_shared(job, slot, o, d, so.origin, so.center, so.radius, so.reach_max, so.sign);
     if (shared == 2) prepare_general(job, slot, o, d, so.center, so.radius);
     if (keys) {
-        // the cell under which the band sweep files the ray (rt_grid.h), 10 bits per axis
-        keys[slot] = rtg::oct_cell_folded(d.x, d.y, d.z, 10);
+        // the cell under which the band sweep files the ray (rt_grid.h)
+        keys[slot] = rtg::oct_cell_folded(d.x, d.y, d.z, so.key_bits);
     }
 }
 
@@ -1896,8 +1897,8 @@ __global__ __launch_bounds__(BLOCK) void shadow_setup_kernel(const int *__restri
     job.tmax[slot] = dist;
     s.occ[slot] = (dist < INFINITY) ? 0 : 1; // `lightRay.t > d` can only hold for finite d
     prepare_shared(job, slot, o2, ld, so.origin, so.center, so.radius, so.reach_max, so.sign);
-    // sorted by the cell of the direction in which the light sees them (rt_grid.h), 10 bits per axis
-    if (keys) keys[slot] = rtg::oct_cell(-ld.x, -ld.y, -ld.z, 10);
+    // sorted by the cell of the direction in which the light sees them (rt_grid.h)
+    if (keys) keys[slot] = rtg::oct_cell(-ld.x, -ld.y, -ld.z, so.key_bits);
 }
 
 // spheres of the shadow trace, then raycol_cs.glsl:50-79 for the rays that reach the light
