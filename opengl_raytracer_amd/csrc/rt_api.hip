@@ -74,7 +74,7 @@ struct rt_ctx {
     bool light_recs_dirty = true;
     // direction cells (rt_grid.h): per shared origin (0 = camera, 1 + a = light a) the list offsets
     // and the lists; grid_bits = 0 turns them off (RT_GRID_BITS)
-    int grid_bits = 8;
+    int grid_bits = 9;
     rtg::CellCone *cell_cones_d = nullptr;
     unsigned int *grid_count_d = nullptr;
     unsigned int *grid_off[1 + RT_MAX_LIGHTS] = {};

@@ -26,7 +26,7 @@
 
 namespace rtg {
 
-constexpr int MAX_BITS = 9;           // cells per axis = 2^bits
+constexpr int MAX_BITS = 10;          // cells per axis = 2^bits
 constexpr double CELL_MARGIN = 4e-6;  // in units of the octahedral square [-1, 1]^2
 
 RT_HD uint32_t spread_bits(uint32_t a)

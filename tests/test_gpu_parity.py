@@ -289,13 +289,15 @@ def test_full_size_filtered_equals_exact_and_is_idempotent(rt):
         assert (pix_a.reshape(-1, 4) != [26, 26, 26, 255]).any(axis=1).mean() > 0.05
 
 
-def test_sorted_ray_paths_against_oracle(rt, oracle_mod, monkeypatch):
+@pytest.mark.parametrize("grid_bits", ["8", "0"], ids=["direction_cells", "streaming_kernels"])
+def test_sorted_ray_paths_against_oracle(rt, oracle_mod, monkeypatch, grid_bits):
     """The clustered mode's sorted-ray kernels (bounce rays sorted by direction for the band sweep,
     shadow rays sorted by the direction in which they leave the light) normally start at 131072 rays
     per launch; RT_SORT_MIN_RAYS lowers that so that a frame the oracle can do exercises them:
     512 x 288 rays, 8 400 triangles, three passes."""
     from opengl_raytracer_amd import scenes
     monkeypatch.setenv("RT_SORT_MIN_RAYS", "4096")
+    monkeypatch.setenv("RT_GRID_BITS", grid_bits)   # 0: no direction cells, the streaming kernels take over
     w, h = 512, 288
     mesh = scenes.concat_meshes(scenes.triangle_soup(8000, seed=99, extent=1.0, size=0.08),
                                 scenes.quad_grid(10, 20, origin=(-1.5, -1.2, 1.2), du=(3.0, 0.0, 0.0), dv=(0.0, 2.4, 0.3)))
@@ -312,9 +314,13 @@ def test_sorted_ray_paths_against_oracle(rt, oracle_mod, monkeypatch):
         assert_same("sorted paths", g, c)
         assert_same_pixels("sorted paths", g, c)
         log = g.kernel_log()
-        # the bounce passes ran as two kernels (band sweep with 4 rays per lane, sphere sweep with 1)
+        # the bounce passes ran as two kernels: band sweep (over direction cells, or streaming with 4 rays
+        # per lane), then sphere sweep
         forms = [(int(r["form"]), int(r["rays_per_lane"])) for r in log if int(r["stage"]) == 1]
-        assert (2, 4) in forms and (2, 1) in forms, forms
+        if grid_bits == "0":
+            assert forms[0] == (1, 4) and (2, 4) in forms and (2, 1) in forms, forms
+        else:
+            assert forms == [(3, 1), (2, 1), (2, 1), (2, 1), (2, 1)], forms
 
 
 # -- error behaviour -----------------------------------------------------------------------
@@ -355,10 +361,10 @@ def test_stage_timers_and_counters(rt):
         assert all(m > 0 for m in ms)
         assert g.stage_ms() == [0.0, 0.0, 0.0]
         log = g.kernel_log()
-        assert [int(x) for x in log["stage"]] == [1, 2, 1, 2]
-        assert (log["ms"] > 0).all() and (log["pairs"] > 0).all()
-        # fresh rays share the camera origin (direction cells), shadow rays the light; bounce rays: clustered
-        assert log["form"][0] == 3 and log["form"][1] == 3 and log["form"][2] == 2
+        # fresh rays share the camera origin (direction cells), shadow rays the light; bounce rays: clustered,
+        # two launches (band sweep, logged with the pass's pairs; sphere sweep, logged with 0)
+        assert [(int(r["stage"]), int(r["form"])) for r in log] == [(1, 3), (2, 3), (1, 2), (1, 2), (2, 3)]
+        assert (log["ms"] > 0).all() and (log["pairs"][[0, 1, 2, 4]] > 0).all()
         assert g.kernel_log().shape[0] == 0
 
 
