@@ -691,7 +691,7 @@ def run_band_cells(fm, tris, org, dirs, bits=8):
     return dict(zip(["pairs", "listed", "passes", "bad"], list(stats)))
 
 
-def in_plane_rays(rs, tris, n_per=4, tilt=(-9, -4)):
+def plane_rays_per_triangle(rs, tris, n_per=4, tilt=(-9, -4)):
     """Rays that start in (or a hair off) a triangle's plane and run along it (or a hair out of it)."""
     t = tris.astype(np.float64)
     e1, e2 = t[:, 1] - t[:, 0], t[:, 2] - t[:, 0]
@@ -715,7 +715,7 @@ def in_plane_rays(rs, tris, n_per=4, tilt=(-9, -4)):
 def test_band_cells_hold_every_member_a_ray_is_inside(fm, bits):
     rs = np.random.RandomState(97)
     tris = np.concatenate([tris_random(rs, 1200, 1.0, 0.05), tris_nasty(rs, 300, 1.0)])
-    org, dirs = in_plane_rays(rs, tris)
+    org, dirs = plane_rays_per_triangle(rs, tris)
     keep = (np.abs(org).max(1) < 1.2) & np.isfinite(dirs).all(1)     # inside the records' range
     _, aimed = rays_through_features(rs, tris, org[:50].astype(np.float64), per_tri=1)
     org = np.concatenate([org[keep], org[keep][:aimed.shape[0]]])
