@@ -3,10 +3,14 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
 
-A step is one whole frame (or one batch of views): raygen, then P x {intersect, color},
-with the scene already resident in HBM, plus -- for N > 1 -- the gather of the RGBA8 rows
-to rank 0 over RCCL.  One process per GPU (torch.distributed, backend nccl); one frame is
-cut into interleaved row tiles over the ranks, so the total work is fixed ("strong").
+A step is one whole frame per GPU (or one batch of views): raygen, then P x {intersect, color},
+with the scene already resident in HBM, plus -- for N > 1 -- the gather of the RGBA8 frames
+to rank 0 over RCCL.  One process per GPU (torch.distributed, backend nccl), scene replicated, no
+collective on the data path.  Two ways to shard (--sharding):
+  batch  (default) every rank renders one whole frame of the workload per step, N frames per step:
+         the work per GPU is fixed ("weak");
+  tiles  ONE frame is cut into interleaved row tiles over the ranks: the total work is fixed ("strong").
+The 64-view workload deals its fixed set of views over the ranks ("strong").
 
 value = rays actually traced (closest-hit rays entering traversal + shadow rays traced,
 summed over passes and ranks) per second of wall time, in Mrays/s.  Rays that missed
@@ -127,6 +131,8 @@ def main():
     ap.add_argument("--workload", default="soup64k_4k_p6")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--trace-mode", type=int, default=2, help="0 filtered, 1 exact, 2 clustered (default)")
+    ap.add_argument("--sharding", choices=("batch", "tiles"), default="batch",
+                    help="N > 1: one whole frame per rank per step (default), or one frame in row tiles")
     args = ap.parse_args()
 
     import torch
@@ -152,9 +158,17 @@ def main():
     g = rt.RayTracer(wl["width"], wl["height"], device=local_rank)
     setup_scene(g, wl)
     g.set_trace_mode(args.trace_mode)
-    if wl["kind"] == "tiles":
+    scaling = "strong"
+    if wl["kind"] == "tiles" and (world == 1 or args.sharding == "tiles"):
         job = sharding.TileShardedFrame(g, wl["width"], wl["height"], dev)
         shard_desc = f"image tiles of {job.tile_rows} rows, interleaved over {world} rank(s), gathered to rank 0"
+        if world == 1:
+            scaling = "weak"  # one rank, one frame: the N = 1 point of the frame-batch series
+    elif wl["kind"] == "tiles":
+        # one whole frame of the workload per rank per step
+        job = sharding.FrameBatch(g, wl["width"], wl["height"], wl["cams"] * world, dev)
+        shard_desc = f"frame batch: {world} frames per step, one per rank, gathered to rank 0"
+        scaling = "weak"
     else:
         job = sharding.FrameBatch(g, wl["width"], wl["height"], wl["cams"], dev)
         shard_desc = f"frame batch: view k on rank k % {world}, frames gathered to rank 0"
@@ -236,10 +250,10 @@ def main():
         out = {
             "metric": METRIC, "value": rays / dt / 1e6, "unit": "Mrays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / steps * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32",
             "data": wl.get("data", "synthetic"),
             "config": {"workload": args.workload, "description": wl["desc"], "width": wl["width"],
-                       "height": wl["height"], "views": len(wl["cams"]), "triangles": int(wl["mesh"].shape[0] // 3),
+                       "height": wl["height"], "views": len(getattr(job, "cameras", wl["cams"])), "triangles": int(wl["mesh"].shape[0] // 3),
                        "passes": wl["passes"], "lights": wl["lights"], "sharding": shard_desc,
                        "trace_mode": ("filtered", "exact", "clustered")[args.trace_mode],
                        "rays_per_step": rays / steps,

@@ -83,6 +83,14 @@ struct rt_ctx {
     void *scan_temp = nullptr;
     size_t scan_temp_bytes = 0;
     rtg::SlotView *slot_views_d = nullptr; // scratch of the list builder, one per slot
+    unsigned int *build_work_d = nullptr;  // ... its (slot, top cell) pairs, and their number at [0] of build_count_d
+    unsigned int *build_count_d = nullptr;
+    unsigned int *build_item_d = nullptr;  // per pair: cells reached, then their exclusive scan
+    unsigned int *build_keys_d = nullptr, *build_keys_out_d = nullptr; // (cell, slot) pairs before / after the sort
+    int *build_vals_d = nullptr;
+    size_t build_pairs_cap = 0;
+    void *build_temp_d = nullptr;
+    size_t build_temp_bytes = 0;
     // direction cells of the band sweep: lists of member records, per mesh
     unsigned int *band_off = nullptr;
     int *band_entries = nullptr;
@@ -386,6 +394,13 @@ extern "C" void rt_destroy(rt_ctx *c)
     (void)hipFree(c->band_off);
     (void)hipFree(c->band_entries);
     (void)hipFree(c->slot_views_d);
+    (void)hipFree(c->build_work_d);
+    (void)hipFree(c->build_count_d);
+    (void)hipFree(c->build_item_d);
+    (void)hipFree(c->build_keys_d);
+    (void)hipFree(c->build_keys_out_d);
+    (void)hipFree(c->build_vals_d);
+    (void)hipFree(c->build_temp_d);
     for (int i = 0; i < 1 + RT_MAX_LIGHTS; i++) {
         (void)hipFree(c->grid_off[i]);
         (void)hipFree(c->grid_entries[i]);
@@ -454,6 +469,8 @@ extern "C" int rt_set_mesh(rt_ctx *c, const rt_vertex *vertices, int num_vertice
     (void)hipFree(c->band_off); c->band_off = nullptr;
     (void)hipFree(c->band_entries); c->band_entries = nullptr;
     (void)hipFree(c->slot_views_d); c->slot_views_d = nullptr;
+    (void)hipFree(c->build_work_d); c->build_work_d = nullptr;
+    (void)hipFree(c->build_item_d); c->build_item_d = nullptr;
     c->num_clusters = 0;
     c->num_vertices = num_vertices;
     c->num_tris = num_vertices / 3;
@@ -917,23 +934,84 @@ static int build_grid(rt_ctx *c, int which, const rtf::ConeRec *cones, const rtf
                        recs, (const int *)c->slot_d, (const rt_vertex *)c->verts, origin[0], origin[1], origin[2], extent,
                        reach_max, c->slot_views_d);
     HIPCHK(c, hipGetLastError());
-    const dim3 grid(cdiv((long long)c->num_slots * BUILD_TOP_CELLS, BLOCK));
-    HIPCHK(c, hipMemsetAsync(c->grid_count_d, 0, (ncells + 2) * sizeof(unsigned int), c->stream));
-    hipLaunchKernelGGL((grid_build_kernel<false>), grid, dim3(BLOCK), 0, c->stream,
-                       (const rtg::CellCone *)c->cell_cones_d, c->grid_bits, (const rtg::SlotView *)c->slot_views_d,
-                       c->num_slots, c->grid_count_d, (const unsigned int *)nullptr, (int *)nullptr);
+    const size_t work_cap = (size_t)c->num_slots * BUILD_TOP_CELLS;
+    if (!c->build_work_d) HIPCHK(c, hipMalloc(&c->build_work_d, work_cap * sizeof(unsigned int)));
+    if (!c->build_item_d) HIPCHK(c, hipMalloc(&c->build_item_d, (work_cap + 1) * sizeof(unsigned int)));
+    if (!c->build_count_d) HIPCHK(c, hipMalloc(&c->build_count_d, sizeof(unsigned int)));
+    HIPCHK(c, hipMemsetAsync(c->build_count_d, 0, sizeof(unsigned int), c->stream));
+    hipLaunchKernelGGL(grid_top_kernel, dim3(cdiv(c->num_slots, (BLOCK / 64) * TOP_SLOTS_PER_WAVE)), dim3(BLOCK), 0,
+                       c->stream, (const rtg::CellCone *)c->cell_cones_d, (const rtg::SlotView *)c->slot_views_d,
+                       c->num_slots, c->build_work_d, c->build_count_d);
     HIPCHK(c, hipGetLastError());
-    size_t total = 0;
-    if (int r = scan_cell_counts(c, c->grid_off[which], &total)) return r;
+    // a handful of pairs per slot survive: size the walk by their number
+    unsigned int *pairs_h = reinterpret_cast<unsigned int *>(c->count_h + 5);
+    HIPCHK(c, hipMemcpyAsync(pairs_h, c->build_count_d, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const size_t items = *pairs_h;
+    const dim3 grid(cdiv((long long)items + 1, BLOCK));
+    hipLaunchKernelGGL((grid_walk_kernel<false>), grid, dim3(BLOCK), 0, c->stream,
+                       (const rtg::CellCone *)c->cell_cones_d, c->grid_bits, (const rtg::SlotView *)c->slot_views_d,
+                       (const unsigned int *)c->build_work_d, (const unsigned int *)c->build_count_d, c->build_item_d,
+                       (const unsigned int *)nullptr, (unsigned int *)nullptr, (int *)nullptr);
+    HIPCHK(c, hipGetLastError());
+    // exclusive scan in place over items + 1 entries: the last one receives the number of pairs
+    {
+        size_t bytes = 0;
+        HIPCHK(c, rocprim::exclusive_scan(nullptr, bytes, c->build_item_d, c->build_item_d, 0u, items + 1,
+                                          rocprim::plus<unsigned int>(), c->stream));
+        if (bytes > c->build_temp_bytes) {
+            (void)hipFree(c->build_temp_d);
+            c->build_temp_d = nullptr;
+            c->build_temp_bytes = bytes + bytes / 4 + 256;
+            HIPCHK(c, hipMalloc(&c->build_temp_d, c->build_temp_bytes));
+        }
+        bytes = c->build_temp_bytes;
+        HIPCHK(c, rocprim::exclusive_scan(c->build_temp_d, bytes, c->build_item_d, c->build_item_d, 0u, items + 1,
+                                          rocprim::plus<unsigned int>(), c->stream));
+    }
+    unsigned int *total_h = reinterpret_cast<unsigned int *>(c->count_h + 4);
+    HIPCHK(c, hipMemcpyAsync(total_h, c->build_item_d + items, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const size_t total = *total_h;
+    if (total > c->build_pairs_cap || !c->build_keys_d) {
+        (void)hipFree(c->build_keys_d); c->build_keys_d = nullptr;
+        (void)hipFree(c->build_keys_out_d); c->build_keys_out_d = nullptr;
+        (void)hipFree(c->build_vals_d); c->build_vals_d = nullptr;
+        c->build_pairs_cap = total + total / 4 + 1024;
+        HIPCHK(c, hipMalloc(&c->build_keys_d, c->build_pairs_cap * sizeof(unsigned int)));
+        HIPCHK(c, hipMalloc(&c->build_keys_out_d, c->build_pairs_cap * sizeof(unsigned int)));
+        HIPCHK(c, hipMalloc(&c->build_vals_d, c->build_pairs_cap * sizeof(int)));
+    }
     if (total > c->grid_cap[which] || !c->grid_entries[which]) {
         (void)hipFree(c->grid_entries[which]);
         c->grid_entries[which] = nullptr;
         c->grid_cap[which] = total + total / 4 + 1024;
         HIPCHK(c, hipMalloc(&c->grid_entries[which], c->grid_cap[which] * sizeof(int)));
     }
-    hipLaunchKernelGGL((grid_build_kernel<true>), grid, dim3(BLOCK), 0, c->stream,
+    hipLaunchKernelGGL((grid_walk_kernel<true>), grid, dim3(BLOCK), 0, c->stream,
                        (const rtg::CellCone *)c->cell_cones_d, c->grid_bits, (const rtg::SlotView *)c->slot_views_d,
-                       c->num_slots, c->grid_count_d, (const unsigned int *)c->grid_off[which], c->grid_entries[which]);
+                       (const unsigned int *)c->build_work_d, (const unsigned int *)c->build_count_d,
+                       (unsigned int *)nullptr, (const unsigned int *)c->build_item_d, c->build_keys_d, c->build_vals_d);
+    HIPCHK(c, hipGetLastError());
+    if (total) {
+        // by cell; the list "everywhere" has key num_cells: one bit more than the cells need
+        const unsigned int key_bits = 2u * (unsigned int)c->grid_bits + 1u;
+        size_t bytes = 0;
+        HIPCHK(c, rocprim::radix_sort_pairs(nullptr, bytes, c->build_keys_d, c->build_keys_out_d, c->build_vals_d,
+                                            c->grid_entries[which], total, 0, key_bits, c->stream));
+        if (bytes > c->build_temp_bytes) {
+            (void)hipFree(c->build_temp_d);
+            c->build_temp_d = nullptr;
+            c->build_temp_bytes = bytes + bytes / 4 + 256;
+            HIPCHK(c, hipMalloc(&c->build_temp_d, c->build_temp_bytes));
+        }
+        bytes = c->build_temp_bytes;
+        HIPCHK(c, rocprim::radix_sort_pairs(c->build_temp_d, bytes, c->build_keys_d, c->build_keys_out_d,
+                                            c->build_vals_d, c->grid_entries[which], total, 0, key_bits, c->stream));
+    }
+    hipLaunchKernelGGL(grid_offsets_kernel, dim3(cdiv((long long)ncells + 2, BLOCK)), dim3(BLOCK), 0, c->stream,
+                       (const unsigned int *)c->build_keys_out_d, (unsigned int)total, (unsigned int)ncells,
+                       c->grid_off[which]);
     HIPCHK(c, hipGetLastError());
     if (getenv("RT_GRID_VERBOSE"))
         fprintf(stderr, "rt: direction cells of origin %d: %zu cells, %zu list entries (%.1f per cell)\n", which, ncells,
@@ -947,7 +1025,7 @@ static int pick_rays_per_wave(int n)
 {
     static const int forced = getenv("RT_RAYS_PER_WAVE") ? atoi(getenv("RT_RAYS_PER_WAVE")) : 0;
     if (forced >= 1 && forced <= 64) return forced;
-    if (n >= 1 << 20) return 64;
+    if (n >= 1 << 21) return 64;
     if (n >= 1 << 18) return 32;
     if (n >= 1 << 16) return 16;
     return 8;

@@ -100,9 +100,7 @@ struct CellCone {
 constexpr int MIN_LEVEL = 2;
 RT_HD size_t level_offset(int level)
 {
-    size_t o = 0;
-    for (int l = MIN_LEVEL; l < level; l++) o += (size_t)1 << (2 * l);
-    return o;
+    return (((size_t)1 << (2 * level)) - ((size_t)1 << (2 * MIN_LEVEL))) / 3; // 4^MIN_LEVEL + ... + 4^(level-1)
 }
 
 RT_HD void make_cell_cone(uint32_t cell, int bits, CellCone *out)

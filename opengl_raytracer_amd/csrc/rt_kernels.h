@@ -906,47 +906,131 @@ __global__ __launch_bounds__(BLOCK) void slot_view_kernel(const float4 *__restri
     views[i] = view;
 }
 
-constexpr int BUILD_TOP_LEVEL = 3; // one thread per (slot or member, cell of this level)
+constexpr int BUILD_TOP_LEVEL = 3; // the builders start one thread per (slot or member, cell of this level)
 constexpr int BUILD_TOP_CELLS = 1 << (2 * BUILD_TOP_LEVEL);
+constexpr unsigned int BUILD_EVERYWHERE = 0xffu;
+constexpr int BUILD_STACK = 3 * (rtg::MAX_BITS - BUILD_TOP_LEVEL) + 8; // entries a walk can have pending
 
-template <bool FILL>
-__global__ __launch_bounds__(BLOCK) void grid_build_kernel(const rtg::CellCone *__restrict__ cells, int bits,
-                                                           const rtg::SlotView *__restrict__ views, int num_slots,
-                                                           unsigned int *__restrict__ count,
-                                                           const unsigned int *__restrict__ off,
-                                                           int *__restrict__ entries)
+// Step 1 of the list build, once per origin: the (slot, top cell) pairs worth walking.  A wavefront
+// takes TOP_SLOTS_PER_WAVE slots in turn, each against the 64 top cells (one read of the slot's view),
+// gathers the pairs that pass in LDS as slot * 256 + top and appends them to `work` with ONE atomic
+// per wavefront (atomics of a launch on one address are served one after the other); a slot for the
+// list "everywhere" is appended once, with top 255.
+constexpr int TOP_SLOTS_PER_WAVE = 16;
+__global__ __launch_bounds__(BLOCK) void grid_top_kernel(const rtg::CellCone *__restrict__ cells,
+                                                         const rtg::SlotView *__restrict__ views, int num_slots,
+                                                         unsigned int *__restrict__ work,
+                                                         unsigned int *__restrict__ work_count)
 {
-    const long long gid = (long long)blockIdx.x * BLOCK + threadIdx.x;
-    // consecutive lanes take consecutive slots against the same top cell: they agree on most tests
-    const int i = (int)(gid % num_slots);
-    const unsigned int top = (unsigned int)(gid / num_slots);
-    if (top >= (unsigned int)BUILD_TOP_CELLS) return;
-    const rtg::SlotView view = views[i];
-    if (view.cone == 0) return;
-    const unsigned int num_cells = 1u << (2 * bits);
-    auto emit = [&](unsigned int cell) {
-        const unsigned int k = atomicAdd(&count[cell], 1u);
-        if (FILL) entries[off[cell] + k] = i;
-    };
-    if (rtg::slot_everywhere(view)) {
-        if (top == 0) emit(num_cells);
+    static_assert(BUILD_TOP_CELLS == 64, "one wavefront per slot");
+    __shared__ unsigned int codes_all[(BLOCK / 64) * TOP_SLOTS_PER_WAVE * 64];
+    const int wave = threadIdx.x >> 6;
+    const unsigned int top = threadIdx.x & 63u;
+    unsigned int *codes = codes_all + wave * TOP_SLOTS_PER_WAVE * 64;
+    const int first = (blockIdx.x * (BLOCK / 64) + wave) * TOP_SLOTS_PER_WAVE;
+    if (first >= num_slots) return;
+    const rtg::CellCone cc = cells[rtg::level_offset(BUILD_TOP_LEVEL) + top];
+    int n = 0; // wave-uniform
+    for (int i = first; i < min(first + TOP_SLOTS_PER_WAVE, num_slots); i++) {
+        const rtg::SlotView view = views[i];
+        bool keep = false;
+        unsigned int code = (unsigned int)i * 256u + top;
+        if (view.cone != 0) {
+            if (rtg::slot_everywhere(view)) {
+                keep = top == 0;
+                code = (unsigned int)i * 256u + BUILD_EVERYWHERE;
+            } else {
+                keep = rtg::cell_meets_slot(cc, view);
+            }
+        }
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+        if (keep) codes[n + lanes_below(m)] = code;
+        n += __popcll(m);
+    }
+    if (!n) return;
+    unsigned int base = 0;
+    if (top == 0) base = atomicAdd(work_count, (unsigned int)n);
+    base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+    for (int k = (int)top; k < n; k += 64) work[base + k] = codes[k];
+}
+
+// Step 2, run twice: one thread per pair walks the cells below its top cell.  FILL = false leaves the
+// number of finest cells it reaches in item_count[t]; FILL = true writes them as (cell, slot) pairs at
+// item_off[t].  The pairs are then sorted by cell (slot order inside a cell: the sort is stable and
+// the walk of a slot's pairs is in slot order only by accident -- nothing depends on the order).
+template <bool FILL>
+__global__ __launch_bounds__(BLOCK) void grid_walk_kernel(const rtg::CellCone *__restrict__ cells, int bits,
+                                                          const rtg::SlotView *__restrict__ views,
+                                                          const unsigned int *__restrict__ work,
+                                                          const unsigned int *__restrict__ work_count,
+                                                          unsigned int *__restrict__ item_count,
+                                                          const unsigned int *__restrict__ item_off,
+                                                          unsigned int *__restrict__ keys, int *__restrict__ vals)
+{
+    // the walk's stack lives in LDS: a register array indexed per lane would be walked lane by lane
+    __shared__ unsigned int stack_all[BUILD_STACK][BLOCK];
+    const unsigned int t = blockIdx.x * BLOCK + threadIdx.x;
+    const unsigned int n_items = *work_count;
+    if (t >= n_items) {
+        if (!FILL && t == n_items) item_count[t] = 0; // the scan's last entry receives the total
         return;
     }
-    unsigned int stack[3 * (rtg::MAX_BITS - BUILD_TOP_LEVEL) + 8]; // (level << 24) | cell
-    int sp = 0;
-    stack[sp++] = ((unsigned int)BUILD_TOP_LEVEL << 24) | top;
-    while (sp > 0) {
-        const unsigned int e = stack[--sp];
-        const int level = (int)(e >> 24);
-        const unsigned int cell = e & 0xffffffu;
-        const rtg::CellCone cc = cells[rtg::level_offset(level) + cell];
-        if (!rtg::cell_meets_slot(cc, view)) continue;
-        if (level == bits) {
-            emit(cell);
+    const unsigned int code = work[t];
+    const int i = (int)(code >> 8);
+    const unsigned int top = code & 0xffu;
+    const unsigned int num_cells = 1u << (2 * bits);
+    unsigned int n = 0;
+    const unsigned int base = FILL ? item_off[t] : 0u;
+    auto emit = [&](unsigned int cell) {
+        if (FILL) {
+            keys[base + n] = cell;
+            vals[base + n] = i;
+        }
+        n++;
+    };
+    if (top == BUILD_EVERYWHERE) {
+        emit(num_cells);
+    } else {
+        const rtg::SlotView view = views[i];
+        unsigned int (*stack)[BLOCK] = stack_all; // [depth][thread]: (level << 24) | cell
+        const int tx = threadIdx.x;
+        int sp = 0;
+        if (bits == BUILD_TOP_LEVEL) {
+            emit(top);
         } else {
-            for (unsigned int k = 0; k < 4; k++) stack[sp++] = ((unsigned int)(level + 1) << 24) | (cell * 4 + k);
+            for (unsigned int k = 0; k < 4; k++)
+                stack[sp++][tx] = ((unsigned int)(BUILD_TOP_LEVEL + 1) << 24) | (top * 4 + k);
+        }
+        while (sp > 0) {
+            const unsigned int e = stack[--sp][tx];
+            const int level = (int)(e >> 24);
+            const unsigned int cell = e & 0xffffffu;
+            const rtg::CellCone cc = cells[rtg::level_offset(level) + cell];
+            if (!rtg::cell_meets_slot(cc, view)) continue;
+            if (level == bits) {
+                emit(cell);
+            } else {
+                for (unsigned int k = 0; k < 4; k++) stack[sp++][tx] = ((unsigned int)(level + 1) << 24) | (cell * 4 + k);
+            }
         }
     }
+    if (!FILL) item_count[t] = n;
+}
+
+// Step 3: off[c] = position of the first pair of cell c in the sorted keys (c = 0 .. num_cells + 1:
+// the list "everywhere" is cell num_cells, and off[num_cells + 1] = total).
+__global__ __launch_bounds__(BLOCK) void grid_offsets_kernel(const unsigned int *__restrict__ keys, unsigned int total,
+                                                             unsigned int num_cells, unsigned int *__restrict__ off)
+{
+    const unsigned int c = blockIdx.x * BLOCK + threadIdx.x;
+    if (c > num_cells + 1) return;
+    unsigned int lo = 0, hi = total; // first position with keys[pos] >= c
+    while (lo < hi) {
+        const unsigned int mid = (lo + hi) >> 1;
+        if (keys[mid] < c) lo = mid + 1;
+        else hi = mid;
+    }
+    off[c] = lo;
 }
 
 // ---------------------------------------------------------------------------
@@ -1600,7 +1684,9 @@ __global__ __launch_bounds__(BLOCK) void band_build_kernel(const rtg::CellCone *
                                                            const unsigned int *__restrict__ off,
                                                            int *__restrict__ entries)
 {
+    __shared__ unsigned int stack_all[BUILD_STACK][BLOCK];
     const long long gid = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    // consecutive lanes take consecutive members (similar normals) against the same top cell
     const int pos = (int)(gid % num_members);
     const unsigned int top = (unsigned int)(gid / num_members);
     if (top >= (unsigned int)BUILD_TOP_CELLS) return;
@@ -1615,11 +1701,12 @@ __global__ __launch_bounds__(BLOCK) void band_build_kernel(const rtg::CellCone *
         if (top == 0) emit(num_cells);
         return;
     }
-    unsigned int stack[3 * (rtg::MAX_BITS - BUILD_TOP_LEVEL) + 8]; // (level << 24) | cell
+    unsigned int (*stack)[BLOCK] = stack_all; // [depth][thread]: (level << 24) | cell
+    const int tx = threadIdx.x;
     int sp = 0;
-    stack[sp++] = ((unsigned int)BUILD_TOP_LEVEL << 24) | top;
+    stack[sp++][tx] = ((unsigned int)BUILD_TOP_LEVEL << 24) | top;
     while (sp > 0) {
-        const unsigned int e = stack[--sp];
+        const unsigned int e = stack[--sp][tx];
         const int level = (int)(e >> 24);
         const unsigned int cell = e & 0xffffffu;
         const rtg::CellCone cc = cells[rtg::level_offset(level) + cell];
@@ -1627,7 +1714,7 @@ __global__ __launch_bounds__(BLOCK) void band_build_kernel(const rtg::CellCone *
         if (level == bits) {
             emit(cell);
         } else {
-            for (unsigned int k = 0; k < 4; k++) stack[sp++] = ((unsigned int)(level + 1) << 24) | (cell * 4 + k);
+            for (unsigned int k = 0; k < 4; k++) stack[sp++][tx] = ((unsigned int)(level + 1) << 24) | (cell * 4 + k);
         }
     }
 }

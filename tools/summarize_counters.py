@@ -30,7 +30,7 @@ for f in ("pmc_sq/sq", "pmc_fetch/f", "pmc_write/w", "pmc_misc/m"):
 lines.append("")
 lines.append("== hardware counters, per launch (each --pmc set collected in a run of its own) ==")
 for k, v in agg.items():
-    if not any(s in k for s in ("traverse", "raygen", "finish", "setup", "cluster")):
+    if not any(s in k for s in ("traverse", "raygen", "finish", "setup", "cluster", "build")):
         continue
     n = max(len(calls[(k, f)]) for f in ("pmc_sq/sq", "pmc_fetch/f", "pmc_write/w", "pmc_misc/m"))
     t, _ = dur.get(k, (float("nan"), 0))
