@@ -230,7 +230,7 @@ def main():
             name = ("closest_hit_kernel" if stage == 1 else "shade_kernel") + \
                    f"<K={k},{('general', 'shared-origin', 'clustered', 'shared-origin direction cells')[form]}{',exact' if exact else ''}>"
             if form == 2:
-                name = "closest_hit_kernel<clustered: traverse_band_kernel + traverse_cluster_kernel per pass>"
+                name = "closest_hit_kernel<clustered: band sweep (traverse_bandcell_kernel) + sphere sweep (traverse_cluster_kernel) per pass>"
             a["launches"] = max(a["launches"], 1)
             kernels.append(dict(kernel=name, launches=a["launches"], avg_ms=a["ms"] / a["launches"],
                                 total_ms=a["ms"], pairs_per_launch=pairs / a["launches"],

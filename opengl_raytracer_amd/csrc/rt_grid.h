@@ -4,20 +4,24 @@
 // point O, and so is every triangle: a cone of directions (rt_filter.h, make_cone_rec) outside of
 // which the edge filter -- hence the reference -- rejects the pair.  The sphere of directions is
 // cut into G x G cells by the octahedral map; for each cell a list holds the slots whose cone
-// shares a direction with the cell.  A ray then looks at the list of its own cell only: what it
-// pays no longer depends on the number of triangles in the scene, nor on what its neighbours in
-// the wavefront look at.
+// and whose edge planes share a direction with the cell.  A ray then looks at the list of its own
+// cell only: what it pays no longer depends on the number of triangles in the scene, nor on what
+// its neighbours in the wavefront look at.
 //
-// Conservativeness.  A ray with float-normalised direction b sits in cell oct_cell(b).  The build
-// lists slot k in cell c unless  angle(axis_c, axis_k) > psi_c + th_k,  where
-//   th_k  = acos(w_k/|a_k| - 2^-20) bounds the angle between a_k and any b that passes the float
-//           test  a_k . b >= w_k  (the same bound make_cluster_cone uses), and
-//   psi_c bounds the angle between axis_c and any direction whose EXACT octahedral coordinates lie
-//           within CELL_MARGIN of the cell's square; the float evaluation in oct_cell is off by
-//           less than 1e-6 of the square's side, CELL_MARGIN is 4e-6.
-// So a (ray, slot) pair missing from the ray's list fails the cone test, which is itself
-// conservative.  The walk down the cone hierarchy (cone per SUPER_RUN slots, per RUN slots, per
-// slot) uses the same test: those cones contain their members' cones by construction.
+// Conservativeness.  A ray with float-normalised direction b sits in cell oct_cell(b).  Every cell
+// (of every level of the grid: a coarser cell is the union of the four below it) has a bounding cone
+// (axis A, half-angle psi) that holds every direction whose EXACT octahedral coordinates lie within
+// CELL_MARGIN of the cell's square; the float evaluation in oct_cell is off by less than 1e-6 of the
+// square's side, CELL_MARGIN is 4e-6.  The build lists slot k in finest cell c unless, for c or a
+// coarser cell above it,
+//   angle(A, axis_k) > psi + th_k,  th_k = acos(w_k/|a_k| - 2^-20) being the bound on the angle between
+//       a_k and any b that passes the float cone test a_k . b >= w_k (as in make_cluster_cone), or
+//   A . n + psi < b_e for one of the triangle's three edge planes (n, b_e) -- see SlotView.
+// So a (ray, slot) pair missing from the ray's list fails the cone test or the edge filter, both of
+// which are conservative.  Slots that no test can bound are on the list "everywhere".
+//
+// The same cells serve the band sweep of arbitrary rays (cell_meets_band): there a list holds the
+// member records whose band of directions shares a direction with the cell.
 //
 // Compiles for the device (hipcc) and for the host (tests/native/filter_model.cpp).
 #pragma once
