@@ -106,6 +106,9 @@ struct rt_ctx {
 
     // rays were written by raygen and not touched since: they share camera_pos as origin
     bool rays_share_camera_origin = false;
+    // the last intersect traced such rays: their hit points follow the pixel order, and so do the
+    // directions in which a light sees them -- the next shading pass does not sort its shadow rays
+    bool hits_follow_pixels = false;
     bool rays_valid = false;
 
     int *list = nullptr;    // compacted ray indices (live rays / rays with a finite origin)
@@ -1208,6 +1211,7 @@ extern "C" int rt_intersect(rt_ctx *c)
         }
     }
     if (int r = stage_end(c, slot)) return r;
+    c->hits_follow_pixels = c->rays_share_camera_origin;
     c->rays_share_camera_origin = false;
     return RT_OK;
 }
@@ -1258,7 +1262,8 @@ extern "C" int rt_color(rt_ctx *c)
                 for (int a = 0; a < c->num_lights; a++) {
                     // in the clustered mode the shadow rays are visited in the order of the direction in
                     // which they leave the light (any order gives the same result)
-                    const bool sorted = c->trace_mode == RT_TRACE_CLUSTERED && n0 >= c->sort_min_rays && c->num_slots >= 8192;
+                    const bool sorted = c->trace_mode == RT_TRACE_CLUSTERED && n0 >= c->sort_min_rays &&
+                                        c->num_slots >= 8192 && !(use_grid(c) && c->hits_follow_pixels);
                     hipLaunchKernelGGL(shadow_setup_kernel, g0, dim3(BLOCK), 0, c->stream, cnt0, c->scratch, c->job,
                                        c->lights[a].pos[0], c->lights[a].pos[1], c->lights[a].pos[2],
                                        shared_origin(c, c->lights[a].pos, -1.0f), c->counters_d,
@@ -1329,6 +1334,7 @@ extern "C" int rt_color(rt_ctx *c)
     if (int r = stage_end(c, slot)) return r;
     // a killed ray keeps its shifted origin: the rays no longer share an origin
     c->rays_share_camera_origin = false;
+    c->hits_follow_pixels = false;
     return RT_OK;
 }
 
