@@ -381,3 +381,63 @@ def test_clustered_equals_all_pairs_on_random_scenes(rt, monkeypatch):
     lines = []
     bad = fuzz_modes.run(1000, 10, log=lines.append)
     assert bad == 0, "\n".join(lines)
+
+
+# -- direction cells ---------------------------------------------------------------------------
+@pytest.mark.parametrize("grid_bits", ["4", "7", "10"])
+def test_direction_cells_at_other_resolutions(rt, oracle_mod, monkeypatch, grid_bits):
+    """The per-cell triangle lists at the coarsest, a middle and the finest grid (the default, 9 bits per
+    axis, is what every other test runs): a camera inside the soup, two lights, three passes."""
+    from opengl_raytracer_amd import scenes
+    monkeypatch.setenv("RT_GRID_BITS", grid_bits)
+    monkeypatch.setenv("RT_SORT_MIN_RAYS", "4096")
+    w, h = 256, 160
+    mesh = scenes.concat_meshes(scenes.triangle_soup(6000, seed=7, extent=1.0, size=0.1),
+                                scenes.quad_grid(8, 8, origin=(-1.5, -1.1, -1.5), du=(3.0, 0.0, 0.0), dv=(0.0, 0.0, 3.0)))
+    cam = scenes.look_at_camera((0.1, 0.0, -0.4), (0.0, 0.1, 0.6))
+    g, c = make_pair(rt, oracle_mod, w, h, threads=16)
+    with g:
+        for o in (g, c):
+            o.set_mesh(mesh)
+            o.set_texture(scenes.noise_texture(64, 64))
+            o.set_lights(scenes.default_lights(), 2)
+            o.set_camera(*cam)
+        g.raygen(); c.raygen()
+        for p in range(3):
+            g.intersect(); c.intersect()
+            assert_same(f"intersect {p}", g, c)
+            g.color(); c.color()
+            assert_same(f"color {p}", g, c)
+            assert_same_pixels(f"color {p}", g, c)
+        forms = {int(r["form"]) for r in g.kernel_log()}
+        assert 3 in forms, forms
+
+
+def test_shadow_rays_from_far_outside_the_scene(rt, oracle_mod):
+    """Shading rays whose origin lies far outside the scene bound: their shadow rays are outside the range
+    the lights' cones were built for and must meet every triangle (the 'wild' path of the direction-cell
+    kernel).  Rays are written by hand and shaded without an intersect pass."""
+    sc = small_scene("mixed")
+    w, h = 128, 4
+    g, c = make_pair(rt, oracle_mod, w, h)
+    rs = np.random.RandomState(5)
+    n = w * h
+    rays = np.zeros(n, dtype=rt.RAY_DTYPE)
+    d = rs.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    # origins 5 to 800 units from the first light, in every direction
+    lpos = np.asarray(sc["lights"][0]["pos"], dtype=np.float64)
+    far = lpos + d * rs.uniform(5.0, 800.0, (n, 1))
+    far[::3] = rs.uniform(-1, 1, (n, 3))[::3]          # a third of them inside the scene
+    rays["origin"] = far
+    rays["dir"] = -d
+    rays["n"] = rs.normal(size=(n, 3))
+    rays["color"] = rs.uniform(0, 1, (n, 3))
+    rays["t"] = 1.0
+    rays["primitiveID"] = rs.randint(0, 40, n)
+    with g:
+        setup(g, sc, 2); setup(c, sc, 2)
+        g.write_rays(rays); c.write_rays(rays)
+        g.color(); c.color()
+        assert_same("color", g, c)
+        assert_same_pixels("color", g, c)
