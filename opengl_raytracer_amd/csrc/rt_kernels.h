@@ -1227,10 +1227,14 @@ __global__ __launch_bounds__(BLOCK) void traverse_grid_kernel(TraverseParams p)
 constexpr int CLUSTER = 32;
 constexpr int NGROUP = 64;
 constexpr int SUBGROUP = 8;
-constexpr int GROUP_TILE = 512; // group records per LDS tile (8 KiB)
+constexpr int GROUP_TILE = 256; // group records per LDS tile (4 KiB)
 
 template <int K, int SWEEPS>
-__global__ __launch_bounds__(BLOCK) void traverse_cluster_kernel(TraverseParams p)
+// The sphere sweep on its own (K = 1, SWEEPS = 2) lives on occupancy -- its member loop waits on record
+// reads -- and fits eight wavefronts per SIMD (64 VGPRs, 17 KiB of LDS per workgroup): 6 % faster than
+// the seven the register allocator settles for.
+__global__ __attribute__((amdgpu_waves_per_eu((K == 1 && SWEEPS == 2) ? 8 : 1, 8)))
+__launch_bounds__(BLOCK) void traverse_cluster_kernel(TraverseParams p)
 {
     constexpr int NR = BLOCK * K;
     __shared__ float4 tile[GROUP_TILE];
