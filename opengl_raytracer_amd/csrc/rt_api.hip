@@ -425,6 +425,9 @@ static int build_band_cells(rt_ctx *c)
     if (!c->grid_bits || !c->num_ngroups) return RT_OK;
     const size_t ncells = (size_t)1 << (2 * c->grid_bits);
     const int members = c->num_ngroups * rtc::NGROUP;
+    // A member sits in about one cell in a hundred of the upper hemisphere; list positions are 32-bit.
+    // Beyond that the streaming band sweep (traverse_band_kernel) takes over.
+    if ((double)members * (double)ncells * 0.005 > 3.0e9) return RT_OK;
     const dim3 grid((unsigned)(((long long)members * BUILD_TOP_CELLS + BLOCK - 1) / BLOCK));
     HIPCHK(c, hipMalloc(&c->band_off, (ncells + 2) * sizeof(unsigned int)));
     HIPCHK(c, hipMemsetAsync(c->grid_count_d, 0, (ncells + 2) * sizeof(unsigned int), c->stream));
