@@ -346,7 +346,6 @@ __device__ __forceinline__ v3 vpos(const rt_vertex *__restrict__ v, int i)
 // ---------------------------------------------------------------------------
 // intersect, part 1 of 3  ("OpenGL Raytracer/rayintersect_cs.glsl":6-12)
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ unsigned int direction_key(float x, float y, float z);
 
 __global__ __launch_bounds__(BLOCK) void intersect_setup_kernel(RaySoA r, const int *__restrict__ list,
                                                                 const int *__restrict__ count, int n_fixed, Job job,
@@ -1943,31 +1942,6 @@ __global__ __launch_bounds__(BLOCK) void color_begin_kernel(RaySoA r, const int 
 }
 
 // raycol_cs.glsl:39-47
-// 20-bit sort key of a unit direction: octahedral map to the unit square, 10 bits per axis,
-// interleaved.  Shadow rays sorted by this key reach the traversal in wavefronts whose rays
-// leave the light in nearly the same direction, so that whole runs of triangles can be skipped.
-__device__ __forceinline__ unsigned int direction_key(float x, float y, float z)
-{
-    const float l1 = fabsf(x) + fabsf(y) + fabsf(z);
-    if (!(l1 > 0.0f) || !(l1 < INFINITY)) return 0xfffffu; // NaN / zero directions last
-    float u = x / l1, v = y / l1;
-    if (z < 0.0f) {
-        const float uu = (1.0f - fabsf(v)) * (u >= 0.0f ? 1.0f : -1.0f);
-        const float vv = (1.0f - fabsf(u)) * (v >= 0.0f ? 1.0f : -1.0f);
-        u = uu; v = vv;
-    }
-    unsigned int qu = (unsigned int)fminf(fmaxf((u * 0.5f + 0.5f) * 1023.0f, 0.0f), 1023.0f);
-    unsigned int qv = (unsigned int)fminf(fmaxf((v * 0.5f + 0.5f) * 1023.0f, 0.0f), 1023.0f);
-    auto spread = [](unsigned int a) {
-        a = (a | (a << 8)) & 0x00FF00FFu;
-        a = (a | (a << 4)) & 0x0F0F0F0Fu;
-        a = (a | (a << 2)) & 0x33333333u;
-        a = (a | (a << 1)) & 0x55555555u;
-        return a;
-    };
-    return spread(qu) | (spread(qv) << 1);
-}
-
 __global__ __launch_bounds__(BLOCK) void shadow_setup_kernel(const int *__restrict__ count, Scratch s, Job job,
                                                              float lx, float ly, float lz, SharedOrigin so,
                                                              unsigned long long *counters, unsigned int *keys)
