@@ -32,6 +32,8 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_TEST = 52.0          # Moller-Trumbore as the reference writes it (trace.glsl:5-20)
 PEAK_FP32_TFLOPS = 157.3      # MI355X vector FP32 peak
+PEAK_HBM_GBS = 8000.0         # MI355X HBM3E
+RAY_PLANE_BYTES = 56.0        # raygen writes 14 float planes per ray
 METRIC = "Mrays/s (primary+secondary) at 4K vs triangle count; % FP32 VALU peak"
 
 
@@ -123,6 +125,40 @@ def cpu_baseline(wl, seconds_hint=15.0):
                       f"{wl['passes']} passes, oracle with {threads} OpenMP threads, {dt:.1f} s"}
 
 
+def per_pair_roofline(g, job, wl, restore_mode):
+    """The brute-force loop proper, measured live: one frame in the per-pair mode (every (ray, triangle)
+    pair goes through a per-pair filter, no group rejection, no lists).  The entry is the closest-hit
+    kernel of the bounce passes (arbitrary rays, general filter): 52 algorithmic FLOP per pair against
+    the FP32 vector peak, durations from hipEvent pairs around each launch."""
+    g.set_trace_mode(0)
+    try:
+        job.render(wl["passes"])
+        g.sync()
+        g.kernel_log()
+        job.render(wl["passes"])
+        g.sync()
+        log = g.kernel_log()
+    finally:
+        g.set_trace_mode(restore_mode)
+        g.counters()
+        g.stage_ms()
+    out = []
+    for form, label in ((0, "bounce passes, general filter"), (1, "primary pass, shared-origin filter")):
+        sel = [r for r in log if int(r["stage"]) == 1 and int(r["form"]) == form and float(r["ms"]) > 0]
+        if not sel:
+            continue
+        ms = sum(float(r["ms"]) for r in sel)
+        pairs = sum(float(r["pairs"]) for r in sel)
+        tf = pairs * FLOP_PER_TEST / (ms * 1e-3) / 1e12
+        out.append({"bound": "valu", "kernel": f"traverse_kernel<K={int(sel[0]['rays_per_lane'])},"
+                                                f"{'general' if form == 0 else 'shared-origin'},closest> ({label})",
+                    "trace_mode": "filtered", "achieved": tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                    "frac": tf / PEAK_FP32_TFLOPS, "traffic": None, "launches": len(sel),
+                    "avg_launch_ms": ms / len(sel), "pairs_per_launch": pairs / len(sel),
+                    "flop_per_pair": FLOP_PER_TEST})
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -130,6 +166,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="soup64k_4k_p6")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-per-pair", action="store_true", help="skip the per-pair-mode roofline frame (N = 1)")
     ap.add_argument("--trace-mode", type=int, default=2, help="0 filtered, 1 exact, 2 clustered (default)")
     ap.add_argument("--sharding", choices=("batch", "tiles"), default="batch",
                     help="N > 1: one whole frame per rank per step (default), or one frame in row tiles")
@@ -258,6 +295,10 @@ def main():
                        "trace_mode": ("filtered", "exact", "clustered")[args.trace_mode],
                        "rays_per_step": rays / steps,
                        "closest_hit_rays_per_step": tot[0] / steps, "shadow_rays_per_step": tot[1] / steps,
+                       # the reference traces a shadow ray per light for every pixel in every pass, dead
+                       # pixels included; the value above counts only the rays this build traces
+                       "rays_per_step_reference_accounting": tot[0] / steps + float(wl["width"]) * wl["height"] *
+                       wl["lights"] * wl["passes"] * len(getattr(job, "cameras", wl["cams"])),
                        "pairs_per_step": (tot[2] + tot[3]) / steps,
                        "filter_pass_rate": (tot[4] + tot[5]) / max(tot[2] + tot[3], 1.0),
                        "slow_steps_per_step": {"closest": tot[6] / steps, "shadow": tot[7] / steps}},
@@ -267,6 +308,17 @@ def main():
             "roofline": roofline,
             "kernels_rank0": kernels[:6],
         }
+        # raygen: 14 planes of one float written per ray, nothing read
+        if stage_ms[0] > 0:
+            gbs = RAY_PLANE_BYTES * g.num_rays * steps * len(getattr(job, "mine", [0])) / (stage_ms[0] * 1e-3) / 1e9
+            out["roofline_raygen"] = {"bound": "hbm", "kernel": "raygen_kernel", "achieved": gbs, "peak": PEAK_HBM_GBS,
+                                      "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
+                                      "avg_launch_ms": stage_ms[0] / (steps * len(getattr(job, "mine", [0]))),
+                                      "bytes_per_launch": RAY_PLANE_BYTES * g.num_rays}
+        if world == 1 and wl["kind"] == "tiles" and args.trace_mode == 2 and not args.no_per_pair:
+            # after the timed region: the same frame in the per-pair mode, for the roofline of the
+            # brute-force loop itself (frac <= 1 by construction)
+            out["roofline_per_pair_mode"] = per_pair_roofline(g, job, wl, args.trace_mode)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl)
         print(json.dumps(out))
