@@ -125,6 +125,19 @@ def cpu_baseline(wl, seconds_hint=15.0):
                       f"{wl['passes']} passes, oracle with {threads} OpenMP threads, {dt:.1f} s"}
 
 
+def measured_traffic(workload_name, kernel_names):
+    """HBM bytes per launch of the named kernels from the committed PMC summary (a separate rocprofv3
+    run of this command: counters cannot be read from inside the benchmark), or None."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic_per_launch.json")))
+        if rec.get("workload") != workload_name:
+            return None, None
+        return (sum(float(rec["kernels"][k]["hbm_bytes_per_launch"]) for k in kernel_names),
+                "profiles/" + rec["source"] + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of this command)")
+    except (OSError, KeyError, ValueError):
+        return None, None
+
+
 def per_pair_roofline(g, job, wl, restore_mode):
     """The brute-force loop proper, measured live: one frame in the per-pair mode (every (ray, triangle)
     pair goes through a per-pair filter, no group rejection, no lists).  The entry is the closest-hit
@@ -275,9 +288,16 @@ def main():
         dom = kernels[0] if kernels else None
         roofline = None
         if dom:
+            names = {"clustered": ["rtk::traverse_bandcell_kernel", "rtk::traverse_cluster_kernel<1, 2>"],
+                     "shade_kernel<K=1,shared-origin direction cells>": ["rtk::traverse_grid_kernel<true>"],
+                     "closest_hit_kernel<K=1,shared-origin direction cells>": ["rtk::traverse_grid_kernel<false>"]}
+            traffic, traffic_src = measured_traffic(
+                args.workload if args.trace_mode == 2 and world == 1 else None,
+                names["clustered"] if "clustered:" in dom["kernel"] else names.get(dom["kernel"], ["?"]))
             roofline = {"bound": "valu", "kernel": dom["kernel"], "achieved": dom["tflops"],
                         "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": dom["tflops"] / PEAK_FP32_TFLOPS,
-                        "traffic": None, "avg_launch_ms": dom["avg_ms"], "launches": dom["launches"],
+                        "traffic": traffic, "traffic_unit": "bytes of HBM per launch", "traffic_source": traffic_src,
+                        "avg_launch_ms": dom["avg_ms"], "launches": dom["launches"],
                         "flop_per_pair": FLOP_PER_TEST, "pairs_per_launch": dom["pairs_per_launch"],
                         "note": "FP32 vector ALU bound (no MFMA). achieved = 52 FLOP (the reference's test as "
                                 "written) x (ray,triangle) pairs decided per launch / launch duration from "
@@ -311,8 +331,9 @@ def main():
         # raygen: 14 planes of one float written per ray, nothing read
         if stage_ms[0] > 0:
             gbs = RAY_PLANE_BYTES * g.num_rays * steps * len(getattr(job, "mine", [0])) / (stage_ms[0] * 1e-3) / 1e9
+            rg_traffic, _ = measured_traffic(args.workload if world == 1 else None, ["rtk::raygen_kernel"])
             out["roofline_raygen"] = {"bound": "hbm", "kernel": "raygen_kernel", "achieved": gbs, "peak": PEAK_HBM_GBS,
-                                      "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
+                                      "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": rg_traffic,
                                       "avg_launch_ms": stage_ms[0] / (steps * len(getattr(job, "mine", [0]))),
                                       "bytes_per_launch": RAY_PLANE_BYTES * g.num_rays}
         if world == 1 and wl["kind"] == "tiles" and args.trace_mode == 2 and not args.no_per_pair:

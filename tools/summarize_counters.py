@@ -1,7 +1,11 @@
 """Summarises the rocprofv3 outputs of tools/prof_counters.sh into one text file.
-usage: python tools/summarize_counters.py gpurun_out/prof_<tag> profiles/<name>.txt"""
+usage: python tools/summarize_counters.py gpurun_out/prof_<tag> profiles/<name>.txt
+Also writes profiles/hbm_traffic_per_launch.json (kernel -> HBM bytes per launch from FETCH_SIZE and
+WRITE_SIZE with the gfx950 corrections), which bench.py quotes as roofline.traffic."""
 import collections
 import csv
+import json
+import os
 import sys
 
 base, out = sys.argv[1], sys.argv[2]
@@ -13,7 +17,8 @@ def short(n):
 
 lines = []
 stats = list(csv.DictReader(open(f"{base}/trace/t_kernel_stats.csv")))
-lines.append("== rocprofv3 --kernel-trace --stats (python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline) ==")
+lines.append("== rocprofv3 --kernel-trace --stats (python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-per-pair) ==")
+traffic = {}
 lines.append(f"{'kernel':70s} {'calls':>6s} {'avg_us':>12s} {'total_ms':>10s} {'%':>6s}")
 for r in stats[:14]:
     lines.append(f"{short(r['Name'])[:70]:70s} {r['Calls']:>6s} {float(r['AverageNs'])/1e3:12.1f} "
@@ -45,6 +50,14 @@ for k, v in agg.items():
     # FETCH_SIZE / WRITE_SIZE are reported in KiB; FETCH_SIZE counts 128-B reads as 64 B on gfx950 (x2)
     lines.append(f"   FETCH_SIZE {per.get('FETCH_SIZE',0)*1024/1e6:.1f} MB raw (x2 for wide coalesced reads on gfx950 = {per.get('FETCH_SIZE',0)*2048/1e6:.1f} MB)"
                  f"   WRITE_SIZE {per.get('WRITE_SIZE',0)*1024/1e6:.1f} MB   -> {(per.get('FETCH_SIZE',0)*2048+per.get('WRITE_SIZE',0)*1024)/t/1e12:.3f} TB/s HBM")
+    if "FETCH_SIZE" in per and "WRITE_SIZE" in per:
+        traffic[k] = {"hbm_bytes_per_launch": per["FETCH_SIZE"] * 2048 + per["WRITE_SIZE"] * 1024,
+                      "launches": n, "avg_ms": t * 1e3}
     lines.append(f"   SQ_LDS_IDX_ACTIVE {per.get('SQ_LDS_IDX_ACTIVE',0):.4g}  SQ_LDS_BANK_CONFLICT {per.get('SQ_LDS_BANK_CONFLICT',0):.4g}")
 open(out, "w").write("\n".join(lines) + "\n")
+json.dump({"source": os.path.basename(out), "workload": "soup64k_4k_p6",
+           "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, one run each; FETCH_SIZE x 2 KiB "
+                   "(128-byte reads count as 64 on gfx950), WRITE_SIZE x 1 KiB; per launch",
+           "kernels": traffic},
+          open(os.path.join(os.path.dirname(out), "hbm_traffic_per_launch.json"), "w"), indent=1)
 print("\n".join(lines))
