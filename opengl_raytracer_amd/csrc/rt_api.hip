@@ -50,6 +50,7 @@ struct rt_ctx {
     bool have_mesh = false;
 
     rtf::TriRec *rec_general = nullptr;
+    rtf::MomRec *rec_moment = nullptr; // per-pair filter of arbitrary rays (moment form)
     rtf::TriRec *rec_camera = nullptr;
     rtf::TriRec *rec_lights = nullptr; // RT_MAX_LIGHTS x rec_stride
     rtf::ConeRec *cone_camera = nullptr;
@@ -369,6 +370,7 @@ extern "C" void rt_destroy(rt_ctx *c)
     (void)hipFree(c->perm_d);
     (void)hipFree(c->verts);
     (void)hipFree(c->rec_general);
+    (void)hipFree(c->rec_moment);
     (void)hipFree(c->rec_camera);
     (void)hipFree(c->rec_lights);
     (void)hipFree(c->cone_camera);
@@ -457,6 +459,7 @@ extern "C" int rt_set_mesh(rt_ctx *c, const rt_vertex *vertices, int num_vertice
     HIPCHK(c, hipStreamSynchronize(c->stream));
     (void)hipFree(c->verts); c->verts = nullptr;
     (void)hipFree(c->rec_general); c->rec_general = nullptr;
+    (void)hipFree(c->rec_moment); c->rec_moment = nullptr;
     (void)hipFree(c->rec_camera); c->rec_camera = nullptr;
     (void)hipFree(c->rec_lights); c->rec_lights = nullptr;
     (void)hipFree(c->cone_camera); c->cone_camera = nullptr;
@@ -529,6 +532,11 @@ extern "C" int rt_set_mesh(rt_ctx *c, const rt_vertex *vertices, int num_vertice
     }
     for (int a = 0; a < 3; a++) c->center[a] = (float)ctr[a];
     c->radius = (float)(std::sqrt(r2) * 1.0001 + 1e-30);
+    HIPCHK(c, hipMalloc(&c->rec_moment, c->rec_stride * sizeof(rtf::MomRec)));
+    if (c->num_tris)
+        hipLaunchKernelGGL(prep_moment_kernel, dim3(cdiv(c->num_tris, BLOCK)), dim3(BLOCK), 0, c->stream, c->verts,
+                           c->num_tris, c->center[0], c->center[1], c->center[2], c->rec_moment);
+    HIPCHK(c, hipGetLastError());
     {
         // plane bands and clusters for the clustered traversal (needs the bounding sphere)
         rtc::ClusterSet cs;
@@ -1189,6 +1197,7 @@ extern "C" int rt_intersect(rt_ctx *c)
             p.count = count;
             p.n = n_upper;
             p.recs = shared ? c->rec_camera : c->rec_general;
+            p.mrecs = c->rec_moment;
             p.cones = c->cone_camera;
             const bool exact = c->trace_mode == RT_TRACE_EXACT;
             // shared origin: the records are in slot order; the all-pairs mode walks the mesh itself

@@ -188,6 +188,75 @@ RT_HD float filter_general(const float *rec, float ox, float oy, float oz, float
     return fmaxf(lo, -hi);
 }
 
+// Moment form of the general filter: the same three triple products from the ray's moment about the
+// centre C of the mesh's bounding sphere, 20 fused operations per pair instead of 23 (no s = o - X, no
+// cross product per pair).  With o' = o - C, X' = X - C and mo = o' x h,
+//     e2'.((o - X) x h) = e2'.mo + (X' x e2').h        e1'.((o - X) x h) = e1'.mo + (X' x e1').h,
+// and the record holds e1', e2' (as in the general record), P1 = X' x e1', P2 = X' x e2' (formed in
+// double, rounded once) and N''.  Rounding, in units of |e'||h| (eps = 2^-24): o' = fl(o - C) moves the
+// origin by eps |o'|; mo carries 4 eps |o'||h|; P by eps |X'||e'|; the six-term fused sum 6 eps times the
+// sum of its terms' magnitudes <= (|o'| + |X'|)|e'||h|: together 11 eps (|o'| + |X'|) per product, twice
+// that for the third (it is formed from the other two and h.N'').  |e'| < sqrt 3 and
+// |o'| + |X'| <= |o - c| + r, so the filter's own share is below 38 eps (|o - c| + r)|d| where the general
+// form's is about 14 eps |s||d|; with the reference's share (the rest of the 80 + 35 above) the
+// difference stays below 160 eps (|o - c| + 3 r)|d| < delta.
+// MomRec = 16 floats: e2'[3], P2[3], e1'[3], P1[3], N''[3], 0.
+struct MomRec {
+    float v[16];
+};
+
+RT_HD void make_moment_rec(const float X[3], const float Y[3], const float Z[3], const float C[3], MomRec *r)
+{
+    float emax;
+    if (degenerate(X, Y, Z, &emax)) {
+        for (int i = 0; i < 16; i++) r->v[i] = fbits(0x7fc00000u);
+        return;
+    }
+    TriRec g;
+    make_general_rec(X, Y, Z, &g); // e1' = v[3..5], e2' = v[6..8], N'' = v[9..11]
+    const double xc[3] = {(double)X[0] - (double)C[0], (double)X[1] - (double)C[1], (double)X[2] - (double)C[2]};
+    const float *e1 = g.v + 3, *e2 = g.v + 6;
+    r->v[0] = e2[0]; r->v[1] = e2[1]; r->v[2] = e2[2];
+    r->v[3] = (float)(xc[1] * e2[2] - xc[2] * e2[1]);
+    r->v[4] = (float)(xc[2] * e2[0] - xc[0] * e2[2]);
+    r->v[5] = (float)(xc[0] * e2[1] - xc[1] * e2[0]);
+    r->v[6] = e1[0]; r->v[7] = e1[1]; r->v[8] = e1[2];
+    r->v[9] = (float)(xc[1] * e1[2] - xc[2] * e1[1]);
+    r->v[10] = (float)(xc[2] * e1[0] - xc[0] * e1[2]);
+    r->v[11] = (float)(xc[0] * e1[1] - xc[1] * e1[0]);
+    r->v[12] = g.v[9]; r->v[13] = g.v[10]; r->v[14] = g.v[11];
+    r->v[15] = 0.0f;
+}
+
+// mo = (o - C) x h, once per ray; (hx,hy,hz) is the direction multiplied by dir_scale()
+RT_HD void ray_moment(float ox, float oy, float oz, const float C[3], float hx, float hy, float hz, float &mx,
+                      float &my, float &mz)
+{
+    const float px = ox - C[0], py = oy - C[1], pz = oz - C[2];
+    mx = fmaf(py, hz, -(pz * hy));
+    my = fmaf(pz, hx, -(px * hz));
+    mz = fmaf(px, hy, -(py * hx));
+}
+
+// lo, hi as filter_general_lohi gives them (same pass rule)
+RT_HD void filter_moment_lohi(const float *rec, float mx, float my, float mz, float hx, float hy, float hz,
+                              float &lo, float &hi)
+{
+    float U = fmaf(rec[2], mz, fmaf(rec[1], my, fmaf(rec[0], mx, fmaf(rec[5], hz, fmaf(rec[4], hy, rec[3] * hx)))));
+    float Vn = fmaf(rec[8], mz, fmaf(rec[7], my, fmaf(rec[6], mx, fmaf(rec[11], hz, fmaf(rec[10], hy, rec[9] * hx)))));
+    float A = fmaf(rec[14], hz, fmaf(rec[13], hy, rec[12] * hx));
+    float W = (-A - U) + Vn;
+    lo = min3f(U, -Vn, W);
+    hi = max3f(U, -Vn, W);
+}
+
+RT_HD float filter_moment(const float *rec, float mx, float my, float mz, float hx, float hy, float hz)
+{
+    float lo, hi;
+    filter_moment_lohi(rec, mx, my, mz, hx, hy, hz, lo, hi);
+    return fmaxf(lo, -hi);
+}
+
 // Shared-origin form: the record was built for origin O and the ray's line
 // passes through O.  (hx,hy,hz) as above.
 RT_HD void filter_origin_lohi(const float *rec, float hx, float hy, float hz, float &lo, float &hi)

@@ -153,6 +153,18 @@ __global__ __launch_bounds__(BLOCK) void prep_general_kernel(const rt_vertex *__
     out[k] = r;
 }
 
+// Moment-form records of the per-pair filter (rt_filter.h, make_moment_rec), in triangle order.
+__global__ __launch_bounds__(BLOCK) void prep_moment_kernel(const rt_vertex *__restrict__ v, int num_tris, float cx,
+                                                            float cy, float cz, rtf::MomRec *__restrict__ out)
+{
+    const int k = blockIdx.x * BLOCK + threadIdx.x;
+    if (k >= num_tris) return;
+    const float C[3] = {cx, cy, cz};
+    rtf::MomRec r;
+    rtf::make_moment_rec(v[3 * k].pos, v[3 * k + 1].pos, v[3 * k + 2].pos, C, &r);
+    out[k] = r;
+}
+
 // Edge and cone records for origin O, in slot order: slot i holds triangle order[i], or nothing
 // (order[i] < 0: a record no ray passes).
 __global__ __launch_bounds__(BLOCK) void prep_origin_kernel(const rt_vertex *__restrict__ v,
@@ -430,21 +442,22 @@ struct TraverseParams {
                                 // inside the member's band and slab <=> max(|n1.b|, |n2.o - kappa'|) < 1
     int num_ngroups;
     const float4 *spheres;      // one (centre, R^2) per cluster of triangles close in space
+    const rtf::MomRec *mrecs;   // per-pair mode, arbitrary rays: moment-form records in triangle order
     const rtf::TriRec *crecs;   // the members' general edge records, CLUSTER per cluster
     const int *members;         // triangle index of each of them, or -1
     int num_clusters;
 };
 
-// cooperative copy of one tile of filter records into LDS; records past the end
-// of the mesh are NaN (no ray passes them)
-__device__ __forceinline__ void load_tile(float4 *tile4, const rtf::TriRec *__restrict__ recs, int tile_base,
-                                          int num_tris, int tid)
+// cooperative copy of one tile of the per-pair filter's 64-byte moment records into LDS; records
+// past the end of the mesh are NaN (no ray passes them)
+__device__ __forceinline__ void load_tile_moment(float4 *tile4, const rtf::MomRec *__restrict__ recs, int tile_base,
+                                                 int num_tris, int tid)
 {
-    const float4 *src = reinterpret_cast<const float4 *>(recs) + (size_t)tile_base * 3;
-    const int avail = (num_tris - tile_base) * 3;
+    const float4 *src = reinterpret_cast<const float4 *>(recs) + (size_t)tile_base * 4;
+    const int avail = (num_tris - tile_base) * 4;
     const float qn = __int_as_float(0x7fc00000);
 #pragma unroll
-    for (int i = 0; i < (TILE * 3) / BLOCK; i++) {
+    for (int i = 0; i < (TILE * 4) / BLOCK; i++) {
         const int e = i * BLOCK + tid;
         tile4[e] = (e < avail) ? src[e] : make_float4(qn, qn, qn, qn);
     }
@@ -490,9 +503,10 @@ template <int K, int FORM, bool ANYHIT, bool EXACT>
 __global__ __attribute__((amdgpu_waves_per_eu((FORM == 1 && !EXACT) ? 6 : 1, (FORM == 1 && !EXACT) ? 6 : 8)))
 __launch_bounds__(BLOCK) void traverse_kernel(TraverseParams p)
 {
-    // FORM 0: tiles of 256 edge records (12 KiB).  FORM 1: tiles of 1024 cone records (16 KiB);
-    // the edge records are only touched by the rare second level and stay in global memory.
-    __shared__ float4 lds4[FORM == 1 ? CONE_TILE : TILE * 3];
+    // FORM 0: tiles of 256 moment records (16 KiB; edge records, 12 KiB, in the all-pairs mode, which
+    // does not read them).  FORM 1: tiles of 1024 cone records (16 KiB); the edge records are only
+    // touched by the rare second level and stay in global memory.
+    __shared__ float4 lds4[FORM == 1 ? CONE_TILE : TILE * 4];
     __shared__ float4 run4[FORM == 1 ? CONE_TILE / RUN : 1];       // FORM 1: the cones of the tile's runs
     __shared__ float4 sup4[FORM == 1 ? CONE_TILE / SUPER_RUN : 1]; // ... and of the level above
     constexpr int TSZ = (FORM == 1) ? CONE_TILE : TILE;
@@ -508,7 +522,8 @@ __launch_bounds__(BLOCK) void traverse_kernel(TraverseParams p)
 
     int slot[K];
     bool valid[K];
-    // FORM 0: a = ray origin, b = direction * g, d = direction.
+    // FORM 0: a = the ray's moment about the mesh centre (rt_filter.h, ray_moment; the ray's origin in
+    // the all-pairs mode), b = direction * g, d = direction.
     // FORM 1: b = unit direction (times dir_sign); a and d are unused.
     float ax[K], ay[K], az[K], bx[K], by[K], bz[K], dx[K], dy[K], dz[K], g[K], tbest[K];
     int idbest[K];
@@ -537,9 +552,13 @@ __launch_bounds__(BLOCK) void traverse_kernel(TraverseParams p)
             v3 oc = rtx::V(o.x - p.center[0], o.y - p.center[1], o.z - p.center[2]);
             const float reach = sqrtf(rtx::dot(oc, oc)) + 3.0f * p.radius;
             g[k] = rtf::dir_scale(reach, d.x, d.y, d.z);
-            ax[k] = o.x; ay[k] = o.y; az[k] = o.z;
             dx[k] = d.x; dy[k] = d.y; dz[k] = d.z;
             bx[k] = d.x * g[k]; by[k] = d.y * g[k]; bz[k] = d.z * g[k];
+            if (EXACT) {
+                ax[k] = o.x; ay[k] = o.y; az[k] = o.z;
+            } else {
+                rtf::ray_moment(o.x, o.y, o.z, p.center, bx[k], by[k], bz[k], ax[k], ay[k], az[k]);
+            }
         } else {
             bx[k] = by[k] = bz[k] = qn;
             g[k] = 1.0f;
@@ -578,7 +597,8 @@ __launch_bounds__(BLOCK) void traverse_kernel(TraverseParams p)
             if (pass[k] && !(ANYHIT && occ[k])) {
                 v3 o, d;
                 if (FORM == 0) {
-                    o = rtx::V(ax[k], ay[k], az[k]);
+                    o = EXACT ? rtx::V(ax[k], ay[k], az[k])
+                              : rtx::V(p.job.ox[slot[k]], p.job.oy[slot[k]], p.job.oz[slot[k]]);
                     d = rtx::V(dx[k], dy[k], dz[k]);
                 } else {
                     o = rtx::V(p.job.ox[slot[k]], p.job.oy[slot[k]], p.job.oz[slot[k]]);
@@ -691,8 +711,8 @@ __launch_bounds__(BLOCK) void traverse_kernel(TraverseParams p)
                 sup4[q] = (p.ccones && sc && q * SUPER_RUN < tile_n) ? sc[tile_base / SUPER_RUN + q]
                                                                      : make_float4(0.0f, 0.0f, 0.0f, -2.0f);
             }
-        } else {
-            load_tile(lds4, p.recs, tile_base, p.num_tris, tid);
+        } else if (!EXACT) {
+            load_tile_moment(lds4, p.mrecs, tile_base, p.num_tris, tid);
         }
         __syncthreads();
         tris_done += tile_n;
@@ -713,11 +733,11 @@ __launch_bounds__(BLOCK) void traverse_kernel(TraverseParams p)
             const float *tile = reinterpret_cast<const float *>(lds4);
 #pragma unroll 2
             for (int j = 0; j < TILE; j++) {
-                const float *rec = tile + j * REC_FLOATS; // wave-uniform address: LDS broadcast
+                const float *rec = tile + j * 16; // wave-uniform address: LDS broadcast
                 float lo[K], hi[K];
 #pragma unroll
                 for (int k = 0; k < K; k++)
-                    rtf::filter_general_lohi(rec, ax[k], ay[k], az[k], bx[k], by[k], bz[k], lo[k], hi[k]);
+                    rtf::filter_moment_lohi(rec, ax[k], ay[k], az[k], bx[k], by[k], bz[k], lo[k], hi[k]);
                 // some ray passes  <=>  max over rays of max(lo, -hi) >= -1
                 float G = fmaxf(lo[0], -hi[0]);
 #pragma unroll

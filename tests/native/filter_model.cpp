@@ -15,17 +15,20 @@ extern "C" int rto_ray_vs_triangle(const float o[3], const float d[3], const flo
 
 static float norm3(const float *v) { return sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
 
-// stats: [0] pairs, [1] filter passes, [2] oracle accepts, [3] violations (accept && !pass)
+// stats: [0] pairs, [1] filter passes, [2] oracle accepts, [3] violations (accept && !pass, either form),
+//        [4] passes of the moment form
 extern "C" void fm_check_general(int n_tris, const float *verts /* n_tris*9 */, int n_rays,
                                  const float *org /* offset origins */, const float *dir,
                                  const float *center, float radius, long long *stats)
 {
-    long long pairs = 0, pass = 0, acc = 0, bad = 0;
-#pragma omp parallel for reduction(+ : pairs, pass, acc, bad) schedule(static)
+    long long pairs = 0, pass = 0, acc = 0, bad = 0, passm = 0;
+#pragma omp parallel for reduction(+ : pairs, pass, acc, bad, passm) schedule(static)
     for (int k = 0; k < n_tris; k++) {
         const float *X = verts + 9 * k, *Y = X + 3, *Z = X + 6;
         rtf::TriRec rec;
         rtf::make_general_rec(X, Y, Z, &rec);
+        rtf::MomRec mrec;
+        rtf::make_moment_rec(X, Y, Z, center, &mrec);
         for (int i = 0; i < n_rays; i++) {
             const float *o = org + 3 * i, *d = dir + 3 * i;
             float oc[3] = {o[0] - center[0], o[1] - center[1], o[2] - center[2]};
@@ -33,15 +36,22 @@ extern "C" void fm_check_general(int n_tris, const float *verts /* n_tris*9 */, 
             float sc = rtf::dir_scale(reach, d[0], d[1], d[2]);
             float g = rtf::filter_general(rec.v, o[0], o[1], o[2], d[0] * sc, d[1] * sc, d[2] * sc);
             bool p = g >= -1.0f;
+            // the moment form of the same filter (the per-pair kernel's): it must let through what the
+            // oracle accepts too
+            float mx, my, mz;
+            rtf::ray_moment(o[0], o[1], o[2], center, d[0] * sc, d[1] * sc, d[2] * sc, mx, my, mz);
+            const bool pm = rtf::filter_moment(mrec.v, mx, my, mz, d[0] * sc, d[1] * sc, d[2] * sc) >= -1.0f;
+            passm += pm;
             float t;
             bool a = rto_ray_vs_triangle(o, d, X, Y, Z, &t) != 0 && t > 0.0f; // trace() keeps t > 0 only
             pairs++;
             pass += p;
             acc += a;
-            bad += (a && !p);
+            bad += (a && !(p && pm));
         }
     }
     stats[0] = pairs; stats[1] = pass; stats[2] = acc; stats[3] = bad;
+    stats[4] = passm;
 }
 
 // Shared-origin form.  org[i] is the origin the reference would use for ray i (it

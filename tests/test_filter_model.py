@@ -79,13 +79,14 @@ def rays_through_features(rs, tris, origins, per_tri=6):
 
 def run_general(fm, tris, org, dirs):
     c, r = bounding_sphere(tris)
-    stats = (C.c_longlong * 4)()
+    stats = (C.c_longlong * 5)()
     tris = np.ascontiguousarray(tris, dtype=f32)
     org = np.ascontiguousarray(org, dtype=f32)
     dirs = np.ascontiguousarray(dirs, dtype=f32)
     fm.fm_check_general(tris.shape[0], tris.ctypes.data, org.shape[0], org.ctypes.data, dirs.ctypes.data,
                         c.ctypes.data, r, stats)
-    return list(stats)
+    run_general.moment_passes = stats[4]  # the moment form of the filter: its pass count, for the selectivity test
+    return list(stats)[:4]
 
 
 def run_origin(fm, tris, O, org, dirs):
@@ -121,6 +122,7 @@ def test_general_form_is_conservative(fm, sc):
     assert bad == 0
     assert acc > 1000               # the feature-aimed rays do exercise accepted pairs
     assert passed < 0.2 * pairs     # and the filter does reject most pairs
+    assert run_general.moment_passes < 0.2 * pairs  # so does its moment form
 
 
 def test_general_form_nasty_triangles(fm):
