@@ -383,6 +383,17 @@ def test_clustered_equals_all_pairs_on_random_scenes(rt, monkeypatch):
     assert bad == 0, "\n".join(lines)
 
 
+def test_per_pair_filters_equal_all_pairs_on_random_scenes(rt):
+    """RT_TRACE_FILTERED (every pair through the shared-origin filter or the moment form of the general
+    filter) against the reference arithmetic on every pair, on the same randomised scenes."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_modes
+    lines = []
+    bad = fuzz_modes.run(1100, 6, log=lines.append, mode=rt.RT_TRACE_FILTERED)
+    assert bad == 0, "\n".join(lines)
+
+
 # -- direction cells ---------------------------------------------------------------------------
 @pytest.mark.parametrize("grid_bits", ["4", "7", "10"])
 def test_direction_cells_at_other_resolutions(rt, oracle_mod, monkeypatch, grid_bits):

@@ -2,7 +2,9 @@
 on the GPU: every ray record and pixel must agree bit for bit.  Scenes vary triangle size, mix
 axis-aligned walls and floors (coplanar with many rays), put lights and cameras inside the geometry,
 and use frames large enough for the sorted-ray kernels.
-usage: python tools/fuzz_modes.py [first_seed] [count]"""
+usage: python tools/fuzz_modes.py [first_seed] [count] [clustered|filtered]
+The third argument picks the mode compared with the all-pairs arithmetic (default: clustered;
+filtered = every pair through the per-pair filters, shared-origin and moment form)."""
 import os
 import sys
 
@@ -39,23 +41,24 @@ def scene(seed):
     return mesh, cam, lights, nl, w, h, int(rs.choice([2, 3, 4]))
 
 
-def run(first, count, log=print):
+def run(first, count, log=print, mode=None):
     """Returns the number of seeds whose two modes disagree."""
     bad_total = 0
+    mode = rt.RT_TRACE_CLUSTERED if mode is None else mode
     for seed in range(first, first + count):
         mesh, cam, lights, nl, w, h, passes = scene(seed)
         out = {}
         with rt.RayTracer(w, h) as g:
             g.set_mesh(mesh); g.set_texture(scenes.noise_texture(64, 64)); g.set_lights(lights, nl); g.set_camera(*cam)
-            for mode in (rt.RT_TRACE_CLUSTERED, rt.RT_TRACE_EXACT):
-                g.set_trace_mode(mode)
+            for m in (mode, rt.RT_TRACE_EXACT):
+                g.set_trace_mode(m)
                 g.raygen()
                 stages = []
                 for p in range(passes):
                     g.intersect(); stages.append(g.read_rays())
                     g.color(); stages.append(g.read_rays())
-                out[mode] = (stages, g.read_pixels())
-        a, b = out[rt.RT_TRACE_CLUSTERED], out[rt.RT_TRACE_EXACT]
+                out[m] = (stages, g.read_pixels())
+        a, b = out[mode], out[rt.RT_TRACE_EXACT]
         msg = "ok"
         for i, (x, y) in enumerate(zip(a[0], b[0])):
             bad = rays_equal_bits(x, y)
@@ -74,4 +77,6 @@ def run(first, count, log=print):
 if __name__ == "__main__":
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-    sys.exit(1 if run(first, count, log=lambda m: print(m, flush=True)) else 0)
+    which = sys.argv[3] if len(sys.argv) > 3 else "clustered"
+    sys.exit(1 if run(first, count, log=lambda m: print(m, flush=True),
+                      mode={"clustered": rt.RT_TRACE_CLUSTERED, "filtered": rt.RT_TRACE_FILTERED}[which]) else 0)
