@@ -126,12 +126,14 @@ def cpu_baseline(wl, seconds_hint=15.0):
 
 
 def measured_traffic(workload_name, kernel_names):
+    measured_traffic.valu_issue = None
     """HBM bytes per launch of the named kernels from the committed PMC summary (a separate rocprofv3
     run of this command: counters cannot be read from inside the benchmark), or None."""
     try:
         rec = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic_per_launch.json")))
         if rec.get("workload") != workload_name:
             return None, None
+        measured_traffic.valu_issue = {k: rec["kernels"][k].get("valu_issue_frac") for k in kernel_names}
         return (sum(float(rec["kernels"][k]["hbm_bytes_per_launch"]) for k in kernel_names),
                 "profiles/" + rec["source"] + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of this command)")
     except (OSError, KeyError, ValueError):
@@ -297,6 +299,8 @@ def main():
             roofline = {"bound": "valu", "kernel": dom["kernel"], "achieved": dom["tflops"],
                         "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": dom["tflops"] / PEAK_FP32_TFLOPS,
                         "traffic": traffic, "traffic_unit": "bytes of HBM per launch", "traffic_source": traffic_src,
+                        # executed VALU wave-instructions / (1024 SIMDs x 0.5 per clock x measured clock), same source
+                        "executed_valu_issue_frac": measured_traffic.valu_issue,
                         "avg_launch_ms": dom["avg_ms"], "launches": dom["launches"],
                         "flop_per_pair": FLOP_PER_TEST, "pairs_per_launch": dom["pairs_per_launch"],
                         "note": "FP32 vector ALU bound (no MFMA). achieved = 52 FLOP (the reference's test as "

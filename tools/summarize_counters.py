@@ -52,7 +52,8 @@ for k, v in agg.items():
                  f"   WRITE_SIZE {per.get('WRITE_SIZE',0)*1024/1e6:.1f} MB   -> {(per.get('FETCH_SIZE',0)*2048+per.get('WRITE_SIZE',0)*1024)/t/1e12:.3f} TB/s HBM")
     if "FETCH_SIZE" in per and "WRITE_SIZE" in per:
         traffic[k] = {"hbm_bytes_per_launch": per["FETCH_SIZE"] * 2048 + per["WRITE_SIZE"] * 1024,
-                      "launches": n, "avg_ms": t * 1e3}
+                      "launches": n, "avg_ms": t * 1e3, "valu_wave_insts_per_launch": valu,
+                      "valu_issue_frac": (valu / t / (1024 * 0.5 * clk)) if clk == clk and clk > 0 else None}
     lines.append(f"   SQ_LDS_IDX_ACTIVE {per.get('SQ_LDS_IDX_ACTIVE',0):.4g}  SQ_LDS_BANK_CONFLICT {per.get('SQ_LDS_BANK_CONFLICT',0):.4g}")
 open(out, "w").write("\n".join(lines) + "\n")
 json.dump({"source": os.path.basename(out), "workload": "soup64k_4k_p6",
