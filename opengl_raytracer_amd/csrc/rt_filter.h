@@ -197,7 +197,7 @@ RT_HD float filter_general(const float *rec, float ox, float oy, float oz, float
 // origin by eps |o'|; mo carries 4 eps |o'||h|; P by eps |X'||e'|; the six-term fused sum 6 eps times the
 // sum of its terms' magnitudes <= (|o'| + |X'|)|e'||h|: together 11 eps (|o'| + |X'|) per product, twice
 // that for the third (it is formed from the other two and h.N'').  |e'| < sqrt 3 and
-// |o'| + |X'| <= |o - c| + r, so the filter's own share is below 38 eps (|o - c| + r)|d| where the general
+// |o'| + |X'| <= |o - c| + r, so the filter's own share is about 38 eps (|o - c| + r)|d| where the general
 // form's is about 14 eps |s||d|; with the reference's share (the rest of the 80 + 35 above) the
 // difference stays below 160 eps (|o - c| + 3 r)|d| < delta.
 // MomRec = 16 floats: e2'[3], P2[3], e1'[3], P1[3], N''[3], 0.
