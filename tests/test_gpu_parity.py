@@ -373,7 +373,7 @@ def test_clustered_equals_all_pairs_on_random_scenes(rt, monkeypatch):
     on randomised scenes: triangle sizes from 0.004 to 0.5, grid floors and walls coplanar with many
     rays, lights and cameras inside the geometry, frames large enough for the sorted-ray kernels
     (tools/fuzz_modes.py runs the same comparison over as many seeds as wanted; 324 seeds passed
-    when this test was written, 400 more -- seeds 2000-2099 and 3000-3299 -- with the direction cells, and seeds 5000-5399 at the final build of the round)."""
+    when this test was written, 400 more -- seeds 2000-2099 and 3000-3299 -- with the direction cells, seeds 5000-5399 and 7000-7399 at the final builds of the round)."""
     import sys
     monkeypatch.setenv("RT_SORT_MIN_RAYS", "16384")
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
