@@ -762,12 +762,19 @@ static int pick_rays_per_lane(int n)
 
 // splits `tiles` LDS tiles over blockIdx.y so that the launch has at least ~2048
 // workgroups (8 per CU): short launches then fill the chip and end together.
-static int pick_tiles_per_y(int ray_blocks, int tiles)
+static int pick_tiles_per_y(int ray_blocks, int tiles, bool sphere_sweep = false)
 {
-    static const int target = [] {
+    static const int target_stream = [] {
         const char *e = getenv("RT_TARGET_BLOCKS");
         return (e && atoi(e) > 0) ? atoi(e) : 8192;
     }();
+    // the sphere sweep's workgroups differ a lot in length (their rays pass different numbers of clusters):
+    // four times as many, shorter ones even out the end of the launch (2.18 -> 2.02 ms per pass at 0.8 M rays)
+    static const int target_sphere = [] {
+        const char *e = getenv("RT_TARGET_BLOCKS_SPHERE");
+        return (e && atoi(e) > 0) ? atoi(e) : 32768;
+    }();
+    const int target = sphere_sweep ? target_sphere : target_stream;
     int want_y = (target + ray_blocks - 1) / ray_blocks;
     if (want_y < 1) want_y = 1;
     if (want_y > tiles) want_y = tiles;
@@ -900,7 +907,7 @@ static int launch_traverse_clustered(rt_ctx *c, TraverseParams p, int n_upper, b
     static const int forced_k = getenv("RT_CLUSTER_K") ? atoi(getenv("RT_CLUSTER_K")) : 0;
     const int k = forced_k == 2 ? 2 : 1;
     const int ray_blocks = cdiv(n_upper, BLOCK * k);
-    p.tiles_per_y = pick_tiles_per_y(ray_blocks, tiles);
+    p.tiles_per_y = pick_tiles_per_y(ray_blocks, tiles, true);
     p.tiles_per_y = (p.tiles_per_y + CONE_TILE / TILE - 1) / (CONE_TILE / TILE) * (CONE_TILE / TILE);
     const dim3 grid(ray_blocks, cdiv(tiles, p.tiles_per_y));
     if (int r = klog_begin(c, 1, 2, k, false, (unsigned long long)n_upper,
