@@ -183,7 +183,9 @@ int rt_get_counters(rt_ctx *ctx, uint64_t counters[8]);
  * the last rt_kernel_log / rt_create (at most the 1024 most recent launches).
  *   stage : 1 = closest-hit traversal (rt_intersect), 2 = shadow traversal + shading (rt_color)
  *   form  : 0 = filter for arbitrary rays, 1 = filter for rays sharing an origin,
- *           2 = clustered traversal of arbitrary rays, 3 = rays sharing an origin,
+ *           2 = clustered traversal of arbitrary rays (its two sweeps run side by side on two
+ *           streams and share one record, from before the first to after the second; one record
+ *           each when RT_SWEEPS_IN_TURN=1 or without band lists), 3 = rays sharing an origin,
  *           each against the triangle list of its direction cell
  *   rays_per_lane : 1, 2 or 4
  *   rays  : rays the launch traversed

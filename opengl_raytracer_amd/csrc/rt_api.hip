@@ -132,6 +132,9 @@ struct rt_ctx {
     unsigned long long *counters_d = nullptr;
 
     hipStream_t stream_own = nullptr;
+    // the two sweeps of a clustered bounce pass run side by side: the sphere sweep on this second stream
+    hipStream_t stream_side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipStream_t stream = nullptr;
 
     int trace_mode = RT_TRACE_CLUSTERED;
@@ -259,6 +262,9 @@ extern "C" int rt_create(rt_ctx **out, int hip_device, int width, int height)
     } while (0)
     CRCHK(hipSetDevice(hip_device));
     CRCHK(hipStreamCreateWithFlags(&c->stream_own, hipStreamNonBlocking));
+    CRCHK(hipStreamCreateWithFlags(&c->stream_side, hipStreamNonBlocking));
+    CRCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    CRCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     c->stream = c->stream_own;
     CRCHK(hipMalloc(&c->planes, 14 * c->stride * sizeof(float)));
     CRCHK(hipMemsetAsync(c->planes, 0, 14 * c->stride * sizeof(float), c->stream));
@@ -357,6 +363,10 @@ extern "C" void rt_destroy(rt_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->stream_side) (void)hipStreamSynchronize(c->stream_side);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->stream_side) (void)hipStreamDestroy(c->stream_side);
     for (auto &p : c->ev_pool) {
         (void)hipEventDestroy(p.a);
         (void)hipEventDestroy(p.b);
@@ -856,9 +866,13 @@ static int launch_traverse_clustered(rt_ctx *c, TraverseParams p, int n_upper, b
     const int tiles = cdiv(p.tri_end - p.tri_begin, TILE);
     if (n_upper <= 0 || tiles <= 0) return RT_OK;
     size_t ks;
+    // With the band lists the two sweeps are two kernels that only meet in `best` (atomicMin): they run
+    // side by side, the sphere sweep on the side stream, and the log holds one record for the pair.
+    static const bool side_by_side = !(getenv("RT_SWEEPS_IN_TURN") && atoi(getenv("RT_SWEEPS_IN_TURN")) != 0);
+    const bool fork = c->band_entries && side_by_side;
     if (c->band_entries) {
         // sweep A over the direction cells (sorted rays share cells, any order gives the same result),
-        // then sweep B
+        // sweep B beside it (or after it)
         TraverseParams a = p;
         a.alist = sorted ? c->sort_slots : nullptr;
         if (sorted) { a.count = nullptr; a.n = n_upper; }
@@ -869,10 +883,15 @@ static int launch_traverse_clustered(rt_ctx *c, TraverseParams p, int n_upper, b
                                (unsigned long long)n_upper * (unsigned long long)(p.tri_end - p.tri_begin), &ks))
             return r;
         a.rays_per_wave = pick_rays_per_wave(n_upper);
+        if (fork) {
+            HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+            HIPCHK(c, hipStreamWaitEvent(c->stream_side, c->ev_fork, 0));
+        }
         hipLaunchKernelGGL(traverse_bandcell_kernel, dim3(cdiv(n_upper, (BLOCK / 64) * a.rays_per_wave)), dim3(BLOCK), 0,
                            c->stream, a);
         HIPCHK(c, hipGetLastError());
-        if (int r = klog_end(c, ks)) return r;
+        if (!fork)
+            if (int r = klog_end(c, ks)) return r;
         p.sweeps = 2;
     } else if (sorted) {
         {
@@ -910,12 +929,19 @@ static int launch_traverse_clustered(rt_ctx *c, TraverseParams p, int n_upper, b
     p.tiles_per_y = pick_tiles_per_y(ray_blocks, tiles, true);
     p.tiles_per_y = (p.tiles_per_y + CONE_TILE / TILE - 1) / (CONE_TILE / TILE) * (CONE_TILE / TILE);
     const dim3 grid(ray_blocks, cdiv(tiles, p.tiles_per_y));
-    if (int r = klog_begin(c, 1, 2, k, false, (unsigned long long)n_upper,
-                           p.sweeps == 2 ? 0ull : (unsigned long long)n_upper * (unsigned long long)(p.tri_end - p.tri_begin), &ks))
-        return r;
+    if (!fork)
+        if (int r = klog_begin(c, 1, 2, k, false, (unsigned long long)n_upper,
+                               p.sweeps == 2 ? 0ull : (unsigned long long)n_upper * (unsigned long long)(p.tri_end - p.tri_begin), &ks))
+            return r;
     if (p.sweeps == 2) {
-        if (k == 2) hipLaunchKernelGGL((traverse_cluster_kernel<2, 2>), grid, dim3(BLOCK), 0, c->stream, p);
-        else hipLaunchKernelGGL((traverse_cluster_kernel<1, 2>), grid, dim3(BLOCK), 0, c->stream, p);
+        hipStream_t st = fork ? c->stream_side : c->stream;
+        if (k == 2) hipLaunchKernelGGL((traverse_cluster_kernel<2, 2>), grid, dim3(BLOCK), 0, st, p);
+        else hipLaunchKernelGGL((traverse_cluster_kernel<1, 2>), grid, dim3(BLOCK), 0, st, p);
+        if (fork) {
+            HIPCHK(c, hipGetLastError());
+            HIPCHK(c, hipEventRecord(c->ev_join, c->stream_side));
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+        }
     } else {
         if (k == 2) hipLaunchKernelGGL((traverse_cluster_kernel<2, 3>), grid, dim3(BLOCK), 0, c->stream, p);
         else hipLaunchKernelGGL((traverse_cluster_kernel<1, 3>), grid, dim3(BLOCK), 0, c->stream, p);

@@ -320,7 +320,9 @@ def test_sorted_ray_paths_against_oracle(rt, oracle_mod, monkeypatch, grid_bits)
         if grid_bits == "0":
             assert forms[0] == (1, 4) and (2, 4) in forms and (2, 1) in forms, forms
         else:
-            assert forms == [(3, 1), (2, 1), (2, 1), (2, 1), (2, 1)], forms
+            # one record per bounce pass when the two sweeps run side by side on two streams (the default),
+            # two when they run in turn (RT_SWEEPS_IN_TURN=1)
+            assert forms in ([(3, 1), (2, 1), (2, 1)], [(3, 1), (2, 1), (2, 1), (2, 1), (2, 1)]), forms
 
 
 # -- error behaviour -----------------------------------------------------------------------
@@ -362,9 +364,12 @@ def test_stage_timers_and_counters(rt):
         assert g.stage_ms() == [0.0, 0.0, 0.0]
         log = g.kernel_log()
         # fresh rays share the camera origin (direction cells), shadow rays the light; bounce rays: clustered,
-        # two launches (band sweep, logged with the pass's pairs; sphere sweep, logged with 0)
-        assert [(int(r["stage"]), int(r["form"])) for r in log] == [(1, 3), (2, 3), (1, 2), (1, 2), (2, 3)]
-        assert (log["ms"] > 0).all() and (log["pairs"][[0, 1, 2, 4]] > 0).all()
+        # one record for the band sweep and the sphere sweep running side by side (two records when they run
+        # in turn, RT_SWEEPS_IN_TURN=1: the band sweep's with the pass's pairs, the sphere sweep's with 0)
+        forms = [(int(r["stage"]), int(r["form"])) for r in log]
+        assert forms in ([(1, 3), (2, 3), (1, 2), (2, 3)], [(1, 3), (2, 3), (1, 2), (1, 2), (2, 3)]), forms
+        with_pairs = [0, 1, 2, 3] if len(forms) == 4 else [0, 1, 2, 4]
+        assert (log["ms"] > 0).all() and (log["pairs"][with_pairs] > 0).all()
         assert g.kernel_log().shape[0] == 0
 
 
