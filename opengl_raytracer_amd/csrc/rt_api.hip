@@ -135,6 +135,8 @@ struct rt_ctx {
     // the two sweeps of a clustered bounce pass run side by side: the sphere sweep on this second stream
     hipStream_t stream_side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool forked = false;   // rt_intersect has already forked the side stream for this pass (before the sort)
+    size_t forked_ks = 0;  // ... and opened this record of the kernel log
     hipStream_t stream = nullptr;
 
     int trace_mode = RT_TRACE_CLUSTERED;
@@ -853,6 +855,23 @@ static int launch_traverse(rt_ctx *c, TraverseParams p, int n_upper, int form, b
 // run the two sweeps as two kernels over two orders of the same rays: the band sweep over rays sorted
 // by direction (a wavefront's rays then share the few groups whose band holds them), the sphere sweep
 // over the pixel-tile order (its rays pass the same clusters).  Both merge into `best` by atomicMin.
+static bool sweeps_side_by_side()
+{
+    static const bool v = !(getenv("RT_SWEEPS_IN_TURN") && atoi(getenv("RT_SWEEPS_IN_TURN")) != 0);
+    return v;
+}
+
+// Opens the kernel-log record of a clustered bounce pass and lets the side stream run from here on.
+static int fork_side_stream(rt_ctx *c, int n_upper, size_t *ks)
+{
+    if (int r = klog_begin(c, 1, 2, 1, false, (unsigned long long)n_upper,
+                           (unsigned long long)n_upper * (unsigned long long)c->num_tris, ks))
+        return r;
+    HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->stream_side, c->ev_fork, 0));
+    return RT_OK;
+}
+
 static int launch_traverse_clustered(rt_ctx *c, TraverseParams p, int n_upper, bool sorted)
 {
     p.ngroups = c->ngroup_d;
@@ -868,8 +887,7 @@ static int launch_traverse_clustered(rt_ctx *c, TraverseParams p, int n_upper, b
     size_t ks;
     // With the band lists the two sweeps are two kernels that only meet in `best` (atomicMin): they run
     // side by side, the sphere sweep on the side stream, and the log holds one record for the pair.
-    static const bool side_by_side = !(getenv("RT_SWEEPS_IN_TURN") && atoi(getenv("RT_SWEEPS_IN_TURN")) != 0);
-    const bool fork = c->band_entries && side_by_side;
+    const bool fork = c->band_entries && sweeps_side_by_side();
     if (c->band_entries) {
         // sweep A over the direction cells (sorted rays share cells, any order gives the same result),
         // sweep B beside it (or after it)
@@ -879,14 +897,17 @@ static int launch_traverse_clustered(rt_ctx *c, TraverseParams p, int n_upper, b
         a.band_off = c->band_off;
         a.band_entries = c->band_entries;
         a.grid_bits = c->grid_bits;
-        if (int r = klog_begin(c, 1, 2, 1, false, (unsigned long long)n_upper,
-                               (unsigned long long)n_upper * (unsigned long long)(p.tri_end - p.tri_begin), &ks))
-            return r;
-        a.rays_per_wave = pick_rays_per_wave(n_upper);
         if (fork) {
-            HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
-            HIPCHK(c, hipStreamWaitEvent(c->stream_side, c->ev_fork, 0));
+            // rt_intersect forks before it sorts the rays for the band sweep (the sphere sweep does not wait
+            // for the sort)
+            if (c->forked) ks = c->forked_ks;
+            else if (int r = fork_side_stream(c, n_upper, &ks)) return r;
+            c->forked = false;
+        } else if (int r = klog_begin(c, 1, 2, 1, false, (unsigned long long)n_upper,
+                                      (unsigned long long)n_upper * (unsigned long long)(p.tri_end - p.tri_begin), &ks)) {
+            return r;
         }
+        a.rays_per_wave = pick_rays_per_wave(n_upper);
         hipLaunchKernelGGL(traverse_bandcell_kernel, dim3(cdiv(n_upper, (BLOCK / 64) * a.rays_per_wave)), dim3(BLOCK), 0,
                            c->stream, a);
         HIPCHK(c, hipGetLastError());
@@ -1219,6 +1240,11 @@ extern "C" int rt_intersect(rt_ctx *c)
                                list, count, n_upper, c->job, c->scratch.best, shared ? 1 : (clustered ? 2 : 0),
                                shared_origin(c, c->cam.pos, 1.0f), sorted ? c->sort_keys : (unsigned int *)nullptr);
             HIPCHK(c, hipGetLastError());
+            c->forked = false;
+            if (clustered && c->band_entries && sweeps_side_by_side()) {
+                if (int r = fork_side_stream(c, n_upper, &c->forked_ks)) return r;
+                c->forked = true;
+            }
             if (sorted) {
                 size_t bytes = c->sort_temp_bytes;
                 HIPCHK(c, rocprim::radix_sort_pairs(c->sort_temp, bytes, c->sort_keys, c->sort_keys_out, c->sort_iota,
