@@ -305,7 +305,8 @@ def main():
                         "flop_per_pair": FLOP_PER_TEST, "pairs_per_launch": dom["pairs_per_launch"],
                         "note": "FP32 vector ALU bound (no MFMA). achieved = 52 FLOP (the reference's test as "
                                 "written) x (ray,triangle) pairs decided per launch / launch duration from "
-                                "hipEvent pairs around each launch on the library's stream. Pairs are mostly "
+                                "hipEvent pairs around each launch on the library's stream (a clustered bounce pass: "
+                                "from the fork of its two side-by-side kernels to their join). Pairs are mostly "
                                 "decided by conservative group tests instead of the 52 FLOPs, so frac exceeds 1; "
                                 "the executed VALU issue rate per kernel is in profiles/*rocprof_summary*.txt"}
         out = {
@@ -334,15 +335,17 @@ def main():
         }
         # raygen: 14 planes of one float written per ray, nothing read
         if stage_ms[0] > 0:
-            gbs = RAY_PLANE_BYTES * g.num_rays * steps * len(getattr(job, "mine", [0])) / (stage_ms[0] * 1e-3) / 1e9
+            frames = max(1, len(getattr(job, "mine", [0])))  # raygen launches per step on this rank
+            gbs = RAY_PLANE_BYTES * g.num_rays * steps * frames / (stage_ms[0] * 1e-3) / 1e9
             rg_traffic, _ = measured_traffic(args.workload if world == 1 else None, ["rtk::raygen_kernel"])
             out["roofline_raygen"] = {"bound": "hbm", "kernel": "raygen_kernel", "achieved": gbs, "peak": PEAK_HBM_GBS,
                                       "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": rg_traffic,
-                                      "avg_launch_ms": stage_ms[0] / (steps * len(getattr(job, "mine", [0]))),
+                                      "avg_launch_ms": stage_ms[0] / (steps * frames),
                                       "bytes_per_launch": RAY_PLANE_BYTES * g.num_rays}
         if world == 1 and wl["kind"] == "tiles" and args.trace_mode == 2 and not args.no_per_pair:
             # after the timed region: the same frame in the per-pair mode, for the roofline of the
-            # brute-force loop itself (frac <= 1 by construction)
+            # brute-force loop itself (the general filter of the bounce passes does its 20 operations on
+            # every pair: frac < 1; the shared-origin filter of the primary pass has a one-operation first level)
             out["roofline_per_pair_mode"] = per_pair_roofline(g, job, wl, args.trace_mode)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl)
