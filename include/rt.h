@@ -102,8 +102,10 @@ int rt_create(rt_ctx **out, int hip_device, int width, int height);
 void rt_destroy(rt_ctx *ctx);
 
 /* Uploads the triangle list: num_vertices 32-byte records, three per triangle
- * (num_vertices % 3 == 0).  Replaces UploadToSSBO + the num_vertices uniform,
- * main.cpp:148-174, 413-414, 496, 505. */
+ * (num_vertices % 3 == 0; fewer than 2^26 triangles, RT_ERR_ARG beyond).  Meshes of
+ * 2^21 triangles or more send their bounce rays through the per-pair filter in every
+ * trace mode.  On failure the context is left without a mesh.  Replaces UploadToSSBO +
+ * the num_vertices uniform, main.cpp:148-174, 413-414, 496, 505. */
 int rt_set_mesh(rt_ctx *ctx, const rt_vertex *vertices, int num_vertices);
 
 /* Uploads the mesh texture as w x h RGBA8 texels, row 0 = bottom row of the
@@ -132,6 +134,31 @@ int rt_num_rays(rt_ctx *ctx);
 int rt_get_row_map(rt_ctx *ctx, int32_t *rows);
 
 int rt_set_trace_mode(rt_ctx *ctx, int mode /* rt_trace_mode */);
+
+/* Tuning, per context.  None of these changes a result bit; they choose between kernels that return
+ * the same rays and pixels.  The reference has no counterpart (its one knob, the thread-group size
+ * baked into the shader header, main.cpp:180-185, has no meaning here).
+ *   RT_OPT_SORT_MIN_RAYS    launches of at least this many rays sort them by direction first
+ *                           (default 131072; >= 1)
+ *   RT_OPT_CLUSTER_MIN_TRIS meshes with fewer triangles send their bounce rays through the per-pair
+ *                           filter instead of the group sweeps (default 1024; >= 0)
+ *   RT_OPT_GRID_BITS        direction cells per axis = 2^bits, 4..10, or 0 = no direction cells: the
+ *                           streaming kernels run instead (default 9)
+ *   RT_OPT_SWEEPS_IN_TURN   1: the two kernels of a clustered bounce pass run one after the other on
+ *                           one stream instead of side by side on two (profiling; default 0)
+ *   RT_OPT_BAND_LIST_MAX    the band sweep's per-cell lists are built only if they hold at most this
+ *                           many entries in total (default and maximum 0xffffff00: list positions
+ *                           are 32-bit); beyond it the streaming band sweep runs
+ * RT_OPT_GRID_BITS and RT_OPT_BAND_LIST_MAX decide what rt_set_mesh builds: after setting one of them
+ * the context has no mesh until the next rt_set_mesh. */
+typedef enum rt_option {
+    RT_OPT_SORT_MIN_RAYS    = 0,
+    RT_OPT_CLUSTER_MIN_TRIS = 1,
+    RT_OPT_GRID_BITS        = 2,
+    RT_OPT_SWEEPS_IN_TURN   = 3,
+    RT_OPT_BAND_LIST_MAX    = 4
+} rt_option;
+int rt_set_option(rt_ctx *ctx, int option /* rt_option */, long long value);
 
 /* The three stages, one call per glDispatchCompute of the reference:
  *   rt_raygen    = raygen_cs.glsl:1-22

@@ -40,6 +40,8 @@ RT_MAX_LIGHTS = 10
 RT_TRACE_FILTERED = 0
 RT_TRACE_EXACT = 1
 RT_TRACE_CLUSTERED = 2
+# rt_option (include/rt.h)
+OPTIONS = {"sort_min_rays": 0, "cluster_min_tris": 1, "grid_bits": 2, "sweeps_in_turn": 3, "band_list_max": 4}
 
 # every symbol include/rt.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
@@ -55,6 +57,7 @@ PROTOTYPES = {
     "rt_num_rays": (C.c_int, [_P]),
     "rt_get_row_map": (C.c_int, [_P, _P]),
     "rt_set_trace_mode": (C.c_int, [_P, C.c_int]),
+    "rt_set_option": (C.c_int, [_P, C.c_int, C.c_longlong]),
     "rt_raygen": (C.c_int, [_P]),
     "rt_intersect": (C.c_int, [_P]),
     "rt_color": (C.c_int, [_P]),

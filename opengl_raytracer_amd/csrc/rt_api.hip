@@ -140,9 +140,14 @@ struct rt_ctx {
     hipStream_t stream = nullptr;
 
     int trace_mode = RT_TRACE_CLUSTERED;
-    // launches with at least this many rays sort them (RT_SORT_MIN_RAYS overrides: tests use a small value)
-    int sort_min_rays = 131072;
-    int cluster_min_tris = 1024;     // smaller meshes: bounce rays take the per-pair filter (RT_CLUSTER_MIN_TRIS)
+    // tuning, per context (rt_set_option)
+    int sort_min_rays = 131072;      // launches with at least this many rays sort them
+    int cluster_min_tris = 1024;     // smaller meshes: bounce rays take the per-pair filter
+    bool sweeps_in_turn = false;     // the two sweeps of a clustered bounce pass one after the other
+    unsigned long long band_list_max = 0xffffff00ull; // longer band lists are not built (32-bit positions)
+    // 64-bit totals of the list builders
+    unsigned long long *sum_d = nullptr;
+    unsigned long long *sum_h = nullptr; // pinned
 
     float acc_ms[3] = {0, 0, 0};
     std::vector<EventPair> ev_pool;
@@ -228,6 +233,40 @@ static int upload_row_map(rt_ctx *c)
     return RT_OK;
 }
 
+// The tables of the direction cells that depend on the resolution only: the cells' bounding cones at
+// every level (one table for every origin), the per-cell counters and the scan's temporary storage.
+static void free_grid_tables(rt_ctx *c)
+{
+    (void)hipFree(c->cell_cones_d); c->cell_cones_d = nullptr;
+    (void)hipFree(c->grid_count_d); c->grid_count_d = nullptr;
+    (void)hipFree(c->scan_temp); c->scan_temp = nullptr;
+    c->scan_temp_bytes = 0;
+    for (int i = 0; i < 1 + RT_MAX_LIGHTS; i++) {
+        (void)hipFree(c->grid_off[i]); c->grid_off[i] = nullptr;
+        (void)hipFree(c->grid_entries[i]); c->grid_entries[i] = nullptr;
+        c->grid_cap[i] = 0;
+    }
+}
+
+static int alloc_grid_tables(rt_ctx *c)
+{
+    if (!c->grid_bits) return RT_OK;
+    const size_t ncells = (size_t)1 << (2 * c->grid_bits);
+    const size_t nall = rtg::level_offset(c->grid_bits) + ncells;
+    std::vector<rtg::CellCone> cc(nall);
+    for (int l = rtg::MIN_LEVEL; l <= c->grid_bits; l++)
+        for (size_t i = 0; i < ((size_t)1 << (2 * l)); i++)
+            rtg::make_cell_cone((uint32_t)i, l, &cc[rtg::level_offset(l) + i]);
+    HIPCHK(c, hipMalloc(&c->cell_cones_d, nall * sizeof(rtg::CellCone)));
+    HIPCHK(c, hipMemcpy(c->cell_cones_d, cc.data(), nall * sizeof(rtg::CellCone), hipMemcpyHostToDevice));
+    // per cell, plus the list "everywhere", plus one for the scan's total
+    HIPCHK(c, hipMalloc(&c->grid_count_d, (ncells + 2) * sizeof(unsigned int)));
+    HIPCHK(c, rocprim::exclusive_scan(nullptr, c->scan_temp_bytes, c->grid_count_d, c->grid_count_d, 0u, ncells + 2,
+                                      rocprim::plus<unsigned int>()));
+    HIPCHK(c, hipMalloc(&c->scan_temp, c->scan_temp_bytes + 256));
+    return RT_OK;
+}
+
 extern "C" int rt_create(rt_ctx **out, int hip_device, int width, int height)
 {
     if (!out) return fail(nullptr, RT_ERR_ARG, "rt_create: out is null");
@@ -276,14 +315,6 @@ extern "C" int rt_create(rt_ctx **out, int hip_device, int width, int height)
     CRCHK(hipMalloc(&c->list, c->cap * sizeof(int)));
     CRCHK(hipMalloc(&c->alist[0], c->cap * sizeof(int)));
     CRCHK(hipMalloc(&c->alist[1], c->cap * sizeof(int)));
-    if (const char *e = getenv("RT_SORT_MIN_RAYS")) {
-        const int v = atoi(e);
-        if (v > 0) c->sort_min_rays = v;
-    }
-    if (const char *e = getenv("RT_CLUSTER_MIN_TRIS")) {
-        const int v = atoi(e);
-        if (v >= 0) c->cluster_min_tris = v;
-    }
     CRCHK(hipMalloc(&c->sort_keys, c->cap * sizeof(unsigned int)));
     CRCHK(hipMalloc(&c->sort_keys_out, c->cap * sizeof(unsigned int)));
     CRCHK(hipMalloc(&c->sort_iota, c->cap * sizeof(int)));
@@ -315,25 +346,12 @@ extern "C" int rt_create(rt_ctx **out, int hip_device, int width, int height)
     }
     CRCHK(hipMalloc(&c->count_d, 8 * sizeof(int)));
     CRCHK(hipHostMalloc(&c->count_h, 8 * sizeof(int)));
-    if (const char *e = getenv("RT_GRID_BITS")) {
-        const int v = atoi(e);
-        if (v == 0 || (v >= 4 && v <= rtg::MAX_BITS)) c->grid_bits = v;
-    }
-    if (c->grid_bits) {
-        // the cells' bounding cones depend on the cell only: one table (every level) for every origin
-        const size_t ncells = (size_t)1 << (2 * c->grid_bits);
-        const size_t nall = rtg::level_offset(c->grid_bits) + ncells;
-        std::vector<rtg::CellCone> cc(nall);
-        for (int l = rtg::MIN_LEVEL; l <= c->grid_bits; l++)
-            for (size_t i = 0; i < ((size_t)1 << (2 * l)); i++)
-                rtg::make_cell_cone((uint32_t)i, l, &cc[rtg::level_offset(l) + i]);
-        CRCHK(hipMalloc(&c->cell_cones_d, nall * sizeof(rtg::CellCone)));
-        CRCHK(hipMemcpy(c->cell_cones_d, cc.data(), nall * sizeof(rtg::CellCone), hipMemcpyHostToDevice));
-        // per cell, plus the list "everywhere", plus one for the scan's total
-        CRCHK(hipMalloc(&c->grid_count_d, (ncells + 2) * sizeof(unsigned int)));
-        CRCHK(rocprim::exclusive_scan(nullptr, c->scan_temp_bytes, c->grid_count_d, c->grid_count_d, 0u, ncells + 2,
-                                      rocprim::plus<unsigned int>()));
-        CRCHK(hipMalloc(&c->scan_temp, c->scan_temp_bytes + 256));
+    CRCHK(hipMalloc(&c->sum_d, sizeof(unsigned long long)));
+    CRCHK(hipHostMalloc(&c->sum_h, sizeof(unsigned long long)));
+    if (alloc_grid_tables(c) != RT_OK) {
+        g_create_error = c->error;
+        rt_destroy(c);
+        return RT_ERR_HIP;
     }
     CRCHK(hipMalloc(&c->fb_own, c->cap * sizeof(uint32_t)));
     CRCHK(hipMemsetAsync(c->fb_own, 0, c->cap * sizeof(uint32_t), c->stream));
@@ -428,20 +446,31 @@ extern "C" void rt_destroy(rt_ctx *c)
     (void)hipFree(c->fb_own);
     (void)hipFree(c->depth);
     (void)hipFree(c->counters_d);
+    (void)hipFree(c->sum_d);
+    if (c->sum_h) (void)hipHostFree(c->sum_h);
     if (c->stream_own) (void)hipStreamDestroy(c->stream_own);
     delete c;
 }
 
 // Lists of the band sweep's direction cells, from the member records of the mesh: count, scan, fill.
 static int scan_cell_counts(rt_ctx *c, unsigned int *off, size_t *total);
+// *total = the sum of n 32-bit counts, in 64 bits (one stream sync)
+static int sum_counts(rt_ctx *c, const unsigned int *v, size_t n, unsigned long long *total)
+{
+    HIPCHK(c, hipMemsetAsync(c->sum_d, 0, sizeof(unsigned long long), c->stream));
+    hipLaunchKernelGGL(sum_counts_kernel, dim3(cdiv((long long)n, BLOCK * 16) > 0 ? cdiv((long long)n, BLOCK * 16) : 1),
+                       dim3(BLOCK), 0, c->stream, v, n, c->sum_d);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->sum_h, c->sum_d, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *total = *c->sum_h;
+    return RT_OK;
+}
 static int build_band_cells(rt_ctx *c)
 {
     if (!c->grid_bits || !c->num_ngroups) return RT_OK;
     const size_t ncells = (size_t)1 << (2 * c->grid_bits);
     const int members = c->num_ngroups * rtc::NGROUP;
-    // A member sits in about one cell in a hundred of the upper hemisphere; list positions are 32-bit.
-    // Beyond that the streaming band sweep (traverse_band_kernel) takes over.
-    if ((double)members * (double)ncells * 0.005 > 3.0e9) return RT_OK;
     const dim3 grid((unsigned)(((long long)members * BUILD_TOP_CELLS + BLOCK - 1) / BLOCK));
     HIPCHK(c, hipMalloc(&c->band_off, (ncells + 2) * sizeof(unsigned int)));
     HIPCHK(c, hipMemsetAsync(c->grid_count_d, 0, (ncells + 2) * sizeof(unsigned int), c->stream));
@@ -449,6 +478,15 @@ static int build_band_cells(rt_ctx *c)
                        (const rtg::CellCone *)c->cell_cones_d, c->grid_bits, (const float4 *)c->nrec_d, members,
                        c->grid_count_d, (const unsigned int *)nullptr, (int *)nullptr);
     HIPCHK(c, hipGetLastError());
+    // List positions are 32-bit: the exact total decides.  Longer lists are not built, and the streaming
+    // band sweep (traverse_band_kernel / traverse_cluster_kernel) takes over.
+    unsigned long long total64 = 0;
+    if (int r = sum_counts(c, c->grid_count_d, ncells + 2, &total64)) return r;
+    if (total64 > c->band_list_max) {
+        (void)hipFree(c->band_off);
+        c->band_off = nullptr;
+        return RT_OK;
+    }
     size_t total = 0;
     if (int r = scan_cell_counts(c, c->band_off, &total)) return r;
     HIPCHK(c, hipMalloc(&c->band_entries, (total + 64) * sizeof(int)));
@@ -456,9 +494,6 @@ static int build_band_cells(rt_ctx *c)
                        (const rtg::CellCone *)c->cell_cones_d, c->grid_bits, (const float4 *)c->nrec_d, members,
                        c->grid_count_d, (const unsigned int *)c->band_off, c->band_entries);
     HIPCHK(c, hipGetLastError());
-    if (getenv("RT_GRID_VERBOSE"))
-        fprintf(stderr, "rt: direction cells of the band sweep: %zu cells, %zu list entries (%.1f per cell)\n", ncells,
-                total, (double)total / (double)ncells);
     return RT_OK;
 }
 
@@ -467,8 +502,15 @@ extern "C" int rt_set_mesh(rt_ctx *c, const rt_vertex *vertices, int num_vertice
     if (!c) return RT_ERR_ARG;
     if (num_vertices < 0 || num_vertices % 3 != 0 || (num_vertices > 0 && !vertices))
         return fail(c, RT_ERR_ARG, "rt_set_mesh: num_vertices=%d must be a non-negative multiple of 3", num_vertices);
+    // the direction-cell kernels queue (triangle, ray) pairs as triangle * 64 + ray in 32 bits
+    if (num_vertices / 3 >= (1 << 26))
+        return fail(c, RT_ERR_ARG, "rt_set_mesh: %d triangles; at most %d are supported", num_vertices / 3,
+                    (1 << 26) - 1);
     if (int r = use_device(c)) return r;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    // until the new mesh is complete the context has none: a failure below leaves it that way
+    c->have_mesh = false;
+    c->num_vertices = c->num_tris = 0;
     (void)hipFree(c->verts); c->verts = nullptr;
     (void)hipFree(c->rec_general); c->rec_general = nullptr;
     (void)hipFree(c->rec_moment); c->rec_moment = nullptr;
@@ -640,7 +682,13 @@ extern "C" int rt_set_camera(rt_ctx *c, const float pos[3], const float dir[3], 
 {
     if (!c) return RT_ERR_ARG;
     if (!pos || !dir || !up || !right) return fail(c, RT_ERR_ARG, "rt_set_camera: null vector");
-    if (!c->have_camera || memcmp(c->cam.pos, pos, sizeof(float) * 3) != 0) c->camera_recs_dirty = true;
+    if (!c->have_camera || memcmp(c->cam.pos, pos, sizeof(float) * 3) != 0) {
+        c->camera_recs_dirty = true;
+        // rays already generated still start at the old position: they no longer pass through the
+        // camera's, and take the traversal of arbitrary rays
+        c->rays_share_camera_origin = false;
+        c->hits_follow_pixels = false;
+    }
     memcpy(c->cam.pos, pos, sizeof(float) * 3);
     memcpy(c->cam.dir, dir, sizeof(float) * 3);
     memcpy(c->cam.up, up, sizeof(float) * 3);
@@ -684,6 +732,45 @@ extern "C" int rt_set_trace_mode(rt_ctx *c, int mode)
         return fail(c, RT_ERR_ARG, "rt_set_trace_mode: unknown mode %d", mode);
     c->trace_mode = mode;
     return RT_OK;
+}
+
+extern "C" int rt_set_option(rt_ctx *c, int option, long long value)
+{
+    if (!c) return RT_ERR_ARG;
+    switch (option) {
+    case RT_OPT_SORT_MIN_RAYS:
+        if (value < 1 || value > (1ll << 30)) break;
+        c->sort_min_rays = (int)value;
+        return RT_OK;
+    case RT_OPT_CLUSTER_MIN_TRIS:
+        if (value < 0 || value > (1ll << 30)) break;
+        c->cluster_min_tris = (int)value;
+        return RT_OK;
+    case RT_OPT_SWEEPS_IN_TURN:
+        if (value != 0 && value != 1) break;
+        c->sweeps_in_turn = value != 0;
+        return RT_OK;
+    case RT_OPT_BAND_LIST_MAX:
+        if (value < 0 || value > 0xffffff00ll) break;
+        c->band_list_max = (unsigned long long)value;
+        c->have_mesh = false; // the lists are built by rt_set_mesh
+        return RT_OK;
+    case RT_OPT_GRID_BITS: {
+        if (!(value == 0 || (value >= 4 && value <= rtg::MAX_BITS))) break;
+        if (int r = use_device(c)) return r;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        free_grid_tables(c);
+        (void)hipFree(c->band_off); c->band_off = nullptr;
+        (void)hipFree(c->band_entries); c->band_entries = nullptr;
+        c->grid_bits = (int)value;
+        c->have_mesh = false; // every list is built for one resolution
+        c->camera_recs_dirty = c->light_recs_dirty = true;
+        return alloc_grid_tables(c);
+    }
+    default:
+        return fail(c, RT_ERR_ARG, "rt_set_option: unknown option %d", option);
+    }
+    return fail(c, RT_ERR_ARG, "rt_set_option: value %lld out of range for option %d", value, option);
 }
 
 // ---- stage timing -----------------------------------------------------------
@@ -765,8 +852,6 @@ extern "C" int rt_raygen(rt_ctx *c)
 // fewer rays give small launches enough lanes to spread over 256 CUs.
 static int pick_rays_per_lane(int n)
 {
-    static const int forced = getenv("RT_FORCE_K") ? atoi(getenv("RT_FORCE_K")) : 0;
-    if (forced == 1 || forced == 2 || forced == 4) return forced;
     if (n >= 65536) return 4;
     if (n >= 16384) return 2;
     return 1;
@@ -776,16 +861,10 @@ static int pick_rays_per_lane(int n)
 // workgroups (8 per CU): short launches then fill the chip and end together.
 static int pick_tiles_per_y(int ray_blocks, int tiles, bool sphere_sweep = false)
 {
-    static const int target_stream = [] {
-        const char *e = getenv("RT_TARGET_BLOCKS");
-        return (e && atoi(e) > 0) ? atoi(e) : 8192;
-    }();
+    const int target_stream = 8192;
     // the sphere sweep's workgroups differ a lot in length (their rays pass different numbers of clusters):
     // four times as many, shorter ones even out the end of the launch (2.18 -> 2.02 ms per pass at 0.8 M rays)
-    static const int target_sphere = [] {
-        const char *e = getenv("RT_TARGET_BLOCKS_SPHERE");
-        return (e && atoi(e) > 0) ? atoi(e) : 32768;
-    }();
+    const int target_sphere = 32768;
     const int target = sphere_sweep ? target_sphere : target_stream;
     int want_y = (target + ray_blocks - 1) / ray_blocks;
     if (want_y < 1) want_y = 1;
@@ -832,6 +911,8 @@ static int launch_traverse(rt_ctx *c, TraverseParams p, int n_upper, int form, b
     p.tiles_per_y = pick_tiles_per_y(ray_blocks, tiles);
     // sub-ranges start on multiples of the larger (cone) tile
     p.tiles_per_y = (p.tiles_per_y + CONE_TILE / TILE - 1) / (CONE_TILE / TILE) * (CONE_TILE / TILE);
+    // the shared-origin form queues pairs as (slot - first slot of the sub-range) * 2048 + ray in 32 bits
+    if (p.tiles_per_y > (1 << 21) / TILE) p.tiles_per_y = (1 << 21) / TILE;
     const dim3 grid(ray_blocks, cdiv(tiles, p.tiles_per_y));
     size_t ks;
     if (int r = klog_begin(c, stage, form, k, c->trace_mode == RT_TRACE_EXACT, (unsigned long long)n_upper,
@@ -855,11 +936,7 @@ static int launch_traverse(rt_ctx *c, TraverseParams p, int n_upper, int form, b
 // run the two sweeps as two kernels over two orders of the same rays: the band sweep over rays sorted
 // by direction (a wavefront's rays then share the few groups whose band holds them), the sphere sweep
 // over the pixel-tile order (its rays pass the same clusters).  Both merge into `best` by atomicMin.
-static bool sweeps_side_by_side()
-{
-    static const bool v = !(getenv("RT_SWEEPS_IN_TURN") && atoi(getenv("RT_SWEEPS_IN_TURN")) != 0);
-    return v;
-}
+static bool sweeps_side_by_side(const rt_ctx *c) { return !c->sweeps_in_turn; }
 
 // Opens the kernel-log record of a clustered bounce pass and lets the side stream run from here on.
 static int fork_side_stream(rt_ctx *c, int n_upper, size_t *ks)
@@ -887,7 +964,7 @@ static int launch_traverse_clustered(rt_ctx *c, TraverseParams p, int n_upper, b
     size_t ks;
     // With the band lists the two sweeps are two kernels that only meet in `best` (atomicMin): they run
     // side by side, the sphere sweep on the side stream, and the log holds one record for the pair.
-    const bool fork = c->band_entries && sweeps_side_by_side();
+    const bool fork = c->band_entries && sweeps_side_by_side(c);
     if (c->band_entries) {
         // sweep A over the direction cells (sorted rays share cells, any order gives the same result),
         // sweep B beside it (or after it)
@@ -922,10 +999,7 @@ static int launch_traverse_clustered(rt_ctx *c, TraverseParams p, int n_upper, b
             a.n = n_upper;
             const int k = 4;
             const int ray_blocks = cdiv(n_upper, BLOCK * k);
-            static const int band_target = [] {
-                const char *e = getenv("RT_TARGET_BLOCKS_BAND");
-                return (e && atoi(e) > 0) ? atoi(e) : 8192;
-            }();
+            const int band_target = 8192;
             int want_y = (band_target + ray_blocks - 1) / ray_blocks;
             const int max_y = cdiv(c->num_ngroups, BAND_TILE_GROUPS);
             if (want_y > max_y) want_y = max_y;
@@ -944,8 +1018,7 @@ static int launch_traverse_clustered(rt_ctx *c, TraverseParams p, int n_upper, b
     // 32 (sphere sweep only) or 48 bytes of LDS per staged ray; one ray per lane keeps seven
     // workgroups on a CU, which hides the latency of the member loops better than two rays per
     // lane save sphere-test overhead
-    static const int forced_k = getenv("RT_CLUSTER_K") ? atoi(getenv("RT_CLUSTER_K")) : 0;
-    const int k = forced_k == 2 ? 2 : 1;
+    const int k = 1;
     const int ray_blocks = cdiv(n_upper, BLOCK * k);
     p.tiles_per_y = pick_tiles_per_y(ray_blocks, tiles, true);
     p.tiles_per_y = (p.tiles_per_y + CONE_TILE / TILE - 1) / (CONE_TILE / TILE) * (CONE_TILE / TILE);
@@ -956,16 +1029,14 @@ static int launch_traverse_clustered(rt_ctx *c, TraverseParams p, int n_upper, b
             return r;
     if (p.sweeps == 2) {
         hipStream_t st = fork ? c->stream_side : c->stream;
-        if (k == 2) hipLaunchKernelGGL((traverse_cluster_kernel<2, 2>), grid, dim3(BLOCK), 0, st, p);
-        else hipLaunchKernelGGL((traverse_cluster_kernel<1, 2>), grid, dim3(BLOCK), 0, st, p);
+        hipLaunchKernelGGL((traverse_cluster_kernel<1, 2>), grid, dim3(BLOCK), 0, st, p);
         if (fork) {
             HIPCHK(c, hipGetLastError());
             HIPCHK(c, hipEventRecord(c->ev_join, c->stream_side));
             HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
         }
     } else {
-        if (k == 2) hipLaunchKernelGGL((traverse_cluster_kernel<2, 3>), grid, dim3(BLOCK), 0, c->stream, p);
-        else hipLaunchKernelGGL((traverse_cluster_kernel<1, 3>), grid, dim3(BLOCK), 0, c->stream, p);
+        hipLaunchKernelGGL((traverse_cluster_kernel<1, 3>), grid, dim3(BLOCK), 0, c->stream, p);
     }
     HIPCHK(c, hipGetLastError());
     return klog_end(c, ks);
@@ -1022,6 +1093,13 @@ static int build_grid(rt_ctx *c, int which, const rtf::ConeRec *cones, const rtf
                        (const unsigned int *)c->build_work_d, (const unsigned int *)c->build_count_d, c->build_item_d,
                        (const unsigned int *)nullptr, (unsigned int *)nullptr, (int *)nullptr);
     HIPCHK(c, hipGetLastError());
+    {
+        unsigned long long total64 = 0;
+        if (int r = sum_counts(c, c->build_item_d, items + 1, &total64)) return r;
+        if (total64 > 0xffffff00ull)
+            return fail(c, RT_ERR_NOMEM, "direction cells: %llu list entries for one origin exceed the 32-bit list "
+                        "positions; lower RT_OPT_GRID_BITS", total64);
+    }
     // exclusive scan in place over items + 1 entries: the last one receives the number of pairs
     {
         size_t bytes = 0;
@@ -1081,18 +1159,12 @@ static int build_grid(rt_ctx *c, int which, const rtf::ConeRec *cones, const rtf
                        (const unsigned int *)c->build_keys_out_d, (unsigned int)total, (unsigned int)ncells,
                        c->grid_off[which]);
     HIPCHK(c, hipGetLastError());
-    if (getenv("RT_GRID_VERBOSE"))
-        fprintf(stderr, "rt: direction cells of origin %d: %zu cells, %zu list entries (%.1f per cell)\n", which, ncells,
-                total, (double)total / (double)ncells);
     return RT_OK;
 }
 
-// Rays per wavefront of the direction-cell kernels: enough wavefronts to hide the list reads of each
-// (RT_RAYS_PER_WAVE overrides: 1..64).
+// Rays per wavefront of the direction-cell kernels: enough wavefronts to hide the list reads of each.
 static int pick_rays_per_wave(int n)
 {
-    static const int forced = getenv("RT_RAYS_PER_WAVE") ? atoi(getenv("RT_RAYS_PER_WAVE")) : 0;
-    if (forced >= 1 && forced <= 64) return forced;
     if (n >= 1 << 21) return 64;
     if (n >= 1 << 18) return 32;
     if (n >= 1 << 16) return 16;
@@ -1234,14 +1306,16 @@ extern "C" int rt_intersect(rt_ctx *c)
         if (n_upper > 0) {
             // a few hundred triangles are streamed through the per-pair filter faster than their groups
             // are swept
-            const bool clustered = !shared && c->trace_mode == RT_TRACE_CLUSTERED && c->num_tris >= c->cluster_min_tris;
+            // (the group sweeps queue pairs as triangle * 2048 + ray in 32 bits: larger meshes take it too)
+            const bool clustered = !shared && c->trace_mode == RT_TRACE_CLUSTERED &&
+                                   c->num_tris >= c->cluster_min_tris && c->num_tris < (1 << 21);
             const bool sorted = clustered && n_upper >= c->sort_min_rays && c->num_ngroups >= 64;
             hipLaunchKernelGGL(intersect_setup_kernel, dim3(cdiv(n_upper, BLOCK)), dim3(BLOCK), 0, c->stream, c->rays,
                                list, count, n_upper, c->job, c->scratch.best, shared ? 1 : (clustered ? 2 : 0),
                                shared_origin(c, c->cam.pos, 1.0f), sorted ? c->sort_keys : (unsigned int *)nullptr);
             HIPCHK(c, hipGetLastError());
             c->forked = false;
-            if (clustered && c->band_entries && sweeps_side_by_side()) {
+            if (clustered && c->band_entries && sweeps_side_by_side(c)) {
                 if (int r = fork_side_stream(c, n_upper, &c->forked_ks)) return r;
                 c->forked = true;
             }
@@ -1290,11 +1364,7 @@ extern "C" int rt_intersect(rt_ctx *c)
 // triangles per shadow chunk: rays found occluded in one chunk are dropped before the next
 static int shadow_chunk_tris(int num_tris)
 {
-    static const int parts = [] {
-        const char *e = getenv("RT_SHADOW_CHUNKS");
-        const int v = e ? atoi(e) : 2;
-        return (v >= 1 && v <= 64) ? v : 2;
-    }();
+    const int parts = 2;
     int chunk = (num_tris + parts - 1) / parts;
     if (chunk < 4096) chunk = 4096;
     return (chunk + CONE_TILE - 1) / CONE_TILE * CONE_TILE;

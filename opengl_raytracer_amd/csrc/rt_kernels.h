@@ -1052,6 +1052,24 @@ __global__ __launch_bounds__(BLOCK) void grid_offsets_kernel(const unsigned int 
     off[c] = lo;
 }
 
+// 64-bit sum of n 32-bit counts (the list builders size their 32-bit list positions with it): one
+// wavefront reduction and one atomic per workgroup.  *out must be zero before the launch.
+__global__ __launch_bounds__(BLOCK) void sum_counts_kernel(const unsigned int *__restrict__ v, size_t n,
+                                                           unsigned long long *__restrict__ out)
+{
+    __shared__ unsigned long long part[BLOCK / 64];
+    unsigned long long s = 0;
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) s += v[i];
+    for (int sh = 32; sh > 0; sh >>= 1) s += __shfl_down(s, sh, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int w = 0; w < BLOCK / 64; w++) t += part[w];
+        if (t) atomicAdd(out, t);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Shared-origin traversal over direction cells.  One ray per lane; wavefronts are independent
 // (no barrier).  The rays of a wavefront are taken cell by cell: the cell's list is read 64 slots

@@ -14,10 +14,15 @@ def _f3(v):
     return a
 
 
+# options every new RayTracer starts with (name -> value, see rt_option in include/rt.h); the test
+# suite lowers thresholds here so that small scenes reach the kernels meant for large ones
+DEFAULT_OPTIONS = {}
+
+
 class RayTracer:
     """One context on one GPU (rt_create ... rt_destroy)."""
 
-    def __init__(self, width, height, device=0):
+    def __init__(self, width, height, device=0, options=None):
         self._lib = _native.load()
         self._ctx = C.c_void_p()
         self.width, self.height = int(width), int(height)
@@ -27,6 +32,8 @@ class RayTracer:
             self._ctx = C.c_void_p()
             raise RtError(rc, msg)
         self._keep = {}
+        for name, value in {**DEFAULT_OPTIONS, **(options or {})}.items():
+            self.set_option(name, value)
 
     # -- plumbing -----------------------------------------------------------
     def _chk(self, rc):
@@ -79,6 +86,10 @@ class RayTracer:
 
     def set_trace_mode(self, mode):
         self._chk(self._lib.rt_set_trace_mode(self._ctx, int(mode)))
+
+    def set_option(self, name, value):
+        """Tuning knob `name` (a key of _native.OPTIONS); grid_bits and band_list_max before set_mesh."""
+        self._chk(self._lib.rt_set_option(self._ctx, _native.OPTIONS[name], int(value)))
 
     @property
     def local_rows(self):

@@ -3,14 +3,16 @@ import sys
 
 import pytest
 
-# The library sends the bounce rays of meshes under 1024 triangles through the per-pair filter.  The
-# small scenes of these tests are there to exercise the group sweeps, so the threshold is lifted;
-# test_small_mesh_default_threshold covers the default.
-os.environ.setdefault("RT_CLUSTER_MIN_TRIS", "0")
-
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+
+# The library sends the bounce rays of meshes under 1024 triangles through the per-pair filter.  The
+# small scenes of these tests are there to exercise the group sweeps, so every context of the suite
+# starts with that threshold at 0 (rt_set_option); test_small_mesh_default_threshold covers the default.
+from opengl_raytracer_amd import raytracer as _raytracer  # noqa: E402
+
+_raytracer.DEFAULT_OPTIONS["cluster_min_tris"] = 0
 
 
 def pytest_configure(config):

@@ -1,0 +1,314 @@
+"""GPU parity, continued: the rules and configurations that need scenes of their own.
+
+  * ties  (trace.glsl:143, :169: strict `t < r.t`, so the first primitive in order keeps an equal t)
+  * the 262 144-triangle, 64-view frame batch (the largest configuration of the benchmark)
+  * the streaming band sweep that takes over when the band lists would outgrow 32-bit positions
+  * a camera moved between raygen and intersect
+  * a caller's stream and framebuffer bound to the context
+  * two processes sharing one GPU, each rendering its row tiles
+
+Same bar as test_gpu_parity.py: every field of every ray record and every pixel bit-equal to the oracle.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from common import describe_mismatch, rays_equal_bits, setup, small_scene
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+f32 = np.float32
+MODES = [(2, "clustered"), (0, "filtered"), (1, "exact")]
+
+
+def same(tag, gpu, cpu, pixels=True):
+    got, want = gpu.read_rays(), cpu.read_rays()
+    bad = rays_equal_bits(got, want)
+    assert not bad.any(), tag + ": " + describe_mismatch(got, want, bad)
+    if pixels:
+        assert np.array_equal(gpu.read_pixels(), cpu.read_pixels()), tag + ": pixels differ"
+
+
+# -- ties ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode,name", MODES, ids=[m[1] for m in MODES])
+@pytest.mark.parametrize("n,order", [(400, "blocks"), (3000, "blocks"), (1500, "interleaved")])
+def test_identical_triangles_lowest_index_wins(rt, oracle_mod, mode, name, n, order):
+    """Every triangle exists twice (k and k + n, or 2k and 2k + 1): every hit is a tie between two
+    identical triangles and the reference's sequential loop keeps the first one."""
+    from opengl_raytracer_amd import scenes
+    base = scenes.concat_meshes(scenes.triangle_soup(n - 32, seed=11, extent=0.9, size=0.12),
+                                scenes.quad_grid(4, 4, origin=(-1.2, -1.2, 1.1), du=(2.4, 0, 0), dv=(0, 2.4, 0)))
+    assert base.shape[0] == 3 * n
+    if order == "blocks":
+        mesh = scenes.concat_meshes(base, base)
+        first_copy = lambda ids: ids < n
+    else:
+        mesh = np.repeat(base.reshape(n, 3), 2, axis=0).reshape(-1)
+        first_copy = lambda ids: ids % 2 == 0
+    w, h = 96, 64
+    g, c = rt.RayTracer(w, h, options={"sort_min_rays": 1024}), oracle_mod.Oracle(w, h, threads=8)
+    with g:
+        g.set_trace_mode(mode)
+        for o in (g, c):
+            o.set_mesh(mesh)
+            o.set_texture(scenes.checker_texture())
+            o.set_lights(scenes.default_lights(), 2)
+            o.set_camera(*scenes.look_at_camera((0.2, 0.1, -2.4), (0, 0, 0)))
+        g.raygen(); c.raygen()
+        for p in range(3):
+            g.intersect(); c.intersect()
+            same(f"intersect {p}", g, c, pixels=False)
+            ids = g.read_rays()["primitiveID"]
+            tri = ids[(ids >= 0) & (ids < 2 * n)]
+            assert (tri.size > 200 or p > 0) and first_copy(tri).all()
+            g.color(); c.color()
+            same(f"color {p}", g, c)
+
+
+@pytest.mark.parametrize("mode,name", MODES, ids=[m[1] for m in MODES])
+def test_triangle_and_sphere_at_equal_t(rt, oracle_mod, mode, name):
+    """A triangle placed so that its computed t equals, bit for bit, the t of sphere 0 for the same ray:
+    the triangle comes first in trace.glsl's order and the sphere's `t < r.t` is false (trace.glsl:169).
+    The plane's position is found by trying neighbouring floats with the oracle's own arithmetic."""
+    o = f32([0.0, -0.7, 0.0])
+    d = f32([0.0, 0.0, 1.0])
+    o_off = (o + d * f32(0.001)).astype(f32)                  # rayintersect_cs.glsl:12
+    hit, ts = oracle_mod.ray_sphere(o_off, d, f32([0.0, -0.7, 2.0]), 0.5)
+    assert hit and ts > 0
+    z0 = f32(o_off[2] + ts)
+    found = None
+    for k in range(-64, 65):
+        z = z0
+        for _ in range(abs(k)):
+            z = np.nextafter(z, f32(np.inf) if k > 0 else f32(-np.inf))
+        tri = f32([[-0.4, -1.1, z], [0.5, -0.9, z], [0.0, 0.2, z]])
+        ok, tt = oracle_mod.ray_vs_triangle(o_off, d, tri[0], tri[1], tri[2])
+        if ok and tt.view(np.uint32) == ts.view(np.uint32):
+            found = tri
+            break
+    assert found is not None, "no plane position reproduces the sphere's t"
+    from opengl_raytracer_amd import scenes
+    # the tying triangle sits in the middle of a mesh of far-away filler triangles
+    filler = scenes.triangle_soup(300, seed=5, extent=0.3, size=0.05)
+    filler["pos"] += f32([3.0, 3.0, -3.0])
+    tie = scenes.pack_vertices(found, [[0, 0], [1, 0], [0, 1]])
+    mesh = scenes.concat_meshes(filler[:450], tie, filler[450:])
+    tie_id = 150
+    w, h = 64, 2
+    rays = np.zeros(w * h, dtype=rt.RAY_DTYPE)
+    rays["origin"] = o
+    rays["dir"] = d
+    rays["primitiveID"] = -1
+    rays["t"] = -1.0
+    # neighbours of the tying ray: some hit the sphere first, some the triangle first
+    rs = np.random.RandomState(2)
+    rays["origin"][1:] += rs.uniform(-0.3, 0.3, (w * h - 1, 3)).astype(f32) * f32([1, 1, 0])
+    g, c = rt.RayTracer(w, h), oracle_mod.Oracle(w, h, threads=2)
+    with g:
+        g.set_trace_mode(mode)
+        for x in (g, c):
+            x.set_mesh(mesh)
+            x.set_texture(scenes.checker_texture())
+            x.set_lights(scenes.default_lights(), 1)
+            x.set_camera((0, 0, -3), (0, 0, 1), (0, 1, 0), (1, 0, 0))
+            x.write_rays(rays)
+            x.intersect()
+        same("intersect", g, c, pixels=False)
+        got = g.read_rays()
+        assert got["primitiveID"][0] == tie_id and got["t"][0].view(np.uint32) == ts.view(np.uint32)
+        assert (got["primitiveID"] == 301).any()      # sphere 0 = numTris + 0 wins for other rays
+        g.color(); c.color()
+        same("color", g, c)
+
+
+# -- 262 144 triangles, 64 views -------------------------------------------------------------------
+def _views_workload():
+    import bench
+    return bench.workload("soup256k_64views_1080p")
+
+
+def test_soup256k_views_frame_batch_against_oracle(rt, oracle_mod):
+    """The benchmark's largest configuration at a size the oracle covers: the 262 144-triangle soup
+    (seed 12346), views 0, 21 and 42 of the 64 cameras, 64 x 36 rays each, rendered through
+    sharding.FrameBatch into a bound device framebuffer (what bench.py does), rays and pixels
+    against the oracle."""
+    import torch
+    from opengl_raytracer_amd import scenes, sharding
+    wl = _views_workload()
+    assert wl["mesh"].shape[0] == 3 * 262144 and len(wl["cams"]) == 64
+    w, h = 64, 36
+    picks = [0, 21, 42]
+    cams = [wl["cams"][k] for k in picks]
+    dev = torch.device("cuda", 0)
+    g, c = rt.RayTracer(w, h), oracle_mod.Oracle(w, h, threads=16)
+    with g:
+        for o in (g, c):
+            o.set_mesh(wl["mesh"])
+            o.set_texture(wl["tex"])
+            o.set_lights(scenes.default_lights(), wl["lights"])
+        job = sharding.FrameBatch(g, w, h, cams, dev)
+        frames = job.render(wl["passes"])
+        g.sync()
+        torch.cuda.synchronize(dev)
+        frames = frames.cpu().numpy()
+        assert frames.shape == (3, h, w, 4)
+        for j, cam in enumerate(cams):
+            c.set_camera(*cam)
+            c.render(wl["passes"])
+            assert np.array_equal(frames[j], c.read_pixels()), f"view {picks[j]}: pixels differ"
+        # the rays of the last view are still in the context
+        same(f"view {picks[-1]}", g, c, pixels=False)
+        assert np.isfinite(c.read_rays()["origin"]).all(axis=1).mean() > 0.15   # the soup fills about a quarter of the frame
+
+
+def test_soup256k_1080p_modes_agree(rt):
+    """The same configuration at its full size, through a size-independent property: one view at
+    1920 x 1080, a subset of row tiles, clustered = filtered = all-pairs exact, bit for bit."""
+    from opengl_raytracer_amd import scenes
+    wl = _views_workload()
+    w, h = wl["width"], wl["height"]
+    with rt.RayTracer(w, h) as g:
+        g.set_mesh(wl["mesh"])
+        g.set_texture(wl["tex"])
+        g.set_lights(scenes.default_lights(), 1)
+        g.set_camera(*wl["cams"][5])
+        g.render(2)
+        full_rays, full_pix = g.read_rays().reshape(h, w), g.read_pixels()
+        g.set_row_tiles(4, 3, 27)
+        rows = g.row_map()
+        out = {}
+        for mode in (2, 0, 1):
+            g.set_trace_mode(mode)
+            g.render(2)
+            out[mode] = (g.read_rays(), g.read_pixels())
+        for mode in (0, 1):
+            bad = rays_equal_bits(out[2][0], out[mode][0])
+            assert not bad.any(), f"mode {mode}: " + describe_mismatch(out[2][0], out[mode][0], bad)
+            assert np.array_equal(out[2][1], out[mode][1])
+        assert not rays_equal_bits(out[2][0], full_rays[rows].reshape(-1)).any()
+        assert np.array_equal(out[2][1], full_pix[rows])
+        assert np.isfinite(full_rays["origin"]).all(axis=-1).mean() > 0.15
+
+
+# -- band lists too long for 32-bit positions ----------------------------------------------------------
+@pytest.mark.parametrize("sort_min", [2048, 1 << 30], ids=["sorted_rays", "unsorted_rays"])
+def test_streaming_band_sweep_when_lists_are_not_built(rt, oracle_mod, sort_min):
+    """RT_OPT_BAND_LIST_MAX = 0 is what a mesh whose band lists would pass 2^32 entries gets: no lists,
+    and the bounce rays' band sweep streams the groups instead (over direction-sorted rays when the
+    launch is large enough, inside the cluster kernel otherwise) -- with the direction cells of the
+    shared origins still in use.  Against the oracle."""
+    from opengl_raytracer_amd import scenes
+    w, h = 320, 200
+    mesh = scenes.concat_meshes(scenes.triangle_soup(7000, seed=21, extent=1.0, size=0.09),
+                                scenes.quad_grid(12, 12, origin=(-1.4, -1.2, 1.3), du=(2.8, 0, 0), dv=(0, 2.4, 0.2)))
+    opts = {"band_list_max": 0, "sort_min_rays": sort_min}
+    g, c = rt.RayTracer(w, h, options=opts), oracle_mod.Oracle(w, h, threads=16)
+    with g:
+        for o in (g, c):
+            o.set_mesh(mesh)
+            o.set_texture(scenes.noise_texture(64, 64))
+            o.set_lights(scenes.default_lights(), 1)
+            o.set_camera(*scenes.look_at_camera((0.1, 0.2, -2.5), (0, 0, 0)))
+        g.kernel_log()
+        g.render(3); c.render(3)
+        same("no band lists", g, c)
+        forms = [int(r["form"]) for r in g.kernel_log() if int(r["stage"]) == 1]
+        assert forms[0] == 3 and 2 in forms[1:], forms
+
+
+# -- a camera moved between raygen and intersect ------------------------------------------------------
+@pytest.mark.parametrize("mode,name", MODES[:2], ids=[m[1] for m in MODES[:2]])
+def test_camera_moved_after_raygen(rt, oracle_mod, mode, name):
+    """raygen, then rt_set_camera with another position, then intersect and color: the rays still start
+    at the old position (the reference's intersect reads each ray's own origin), while camera_pos --
+    the depth plane's reference point and the view vector of the shading -- is the new one."""
+    sc = small_scene("mixed")
+    w, h = 96, 80
+    g, c = rt.RayTracer(w, h), oracle_mod.Oracle(w, h, threads=8)
+    pos, d, u, r = sc["cam"]
+    moved = (pos + f32([0.4, -0.3, 0.5]), d, u, r)
+    with g:
+        g.set_trace_mode(mode)
+        setup(g, sc, 2); setup(c, sc, 2)
+        g.render(1); c.render(1)            # lists of the first position exist
+        for o in (g, c):
+            o.raygen()
+            o.set_camera(*moved)
+            o.intersect()
+        same("intersect after move", g, c, pixels=False)
+        dg, dc = g.read_depth(), c.read_depth()
+        assert ((dg.view(np.uint32) == dc.view(np.uint32)) | (np.isnan(dg) & np.isnan(dc))).all()
+        for o in (g, c):
+            o.color()
+            o.intersect()
+            o.color()
+        same("second pass after move", g, c)
+        # and a whole frame from the new position
+        g.render(2); c.render(2)
+        same("frame from the new position", g, c)
+
+
+# -- a caller's stream and framebuffer ---------------------------------------------------------------
+@pytest.mark.parametrize("in_turn", [0, 1], ids=["side_by_side", "in_turn"])
+def test_bound_stream_and_framebuffer(rt, oracle_mod, in_turn):
+    """rt_bind_stream with a torch stream and rt_bind_framebuffer with a torch tensor: the stage calls
+    enqueue on the caller's stream (the library's internal side stream forks from it and joins it),
+    pixels land in the caller's tensor; three passes of a scene whose bounce rays take the group
+    sweeps, launches large enough to sort.  Then rt_unbind_stream / the own framebuffer again."""
+    import torch
+    from opengl_raytracer_amd import scenes
+    w, h = 384, 256
+    mesh = scenes.concat_meshes(scenes.triangle_soup(6000, seed=33, extent=1.0, size=0.1),
+                                scenes.quad_grid(8, 8, origin=(-1.5, -1.3, 1.2), du=(3.0, 0, 0), dv=(0, 2.6, 0)))
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    fb = torch.zeros((h, w, 4), dtype=torch.uint8, device=dev)
+    g = rt.RayTracer(w, h, options={"sort_min_rays": 2048, "sweeps_in_turn": in_turn})
+    c = oracle_mod.Oracle(w, h, threads=16)
+    with g:
+        for o in (g, c):
+            o.set_mesh(mesh)
+            o.set_texture(scenes.noise_texture(64, 64))
+            o.set_lights(scenes.default_lights(), 2)
+            o.set_camera(*scenes.look_at_camera((0.3, 0.1, -2.6), (0, 0, 0)))
+        c.render(3)
+        g.bind_stream(stream.cuda_stream)
+        g.bind_framebuffer(fb.data_ptr())
+        with torch.cuda.stream(stream):
+            g.render(3)
+            host = fb.cpu()                 # ordered after the render on the same stream
+        stream.synchronize()
+        assert np.array_equal(host.numpy(), c.read_pixels())
+        same("bound stream", g, c, pixels=False)
+        forms = [int(r["form"]) for r in g.kernel_log() if int(r["stage"]) == 1]
+        assert forms.count(2) == (4 if in_turn else 2), forms
+        # back to the context's own stream and framebuffer
+        g.unbind_stream()
+        g.bind_framebuffer(0)
+        g.render(3)
+        same("own stream again", g, c)
+        assert np.array_equal(fb.cpu().numpy(), c.read_pixels())   # the caller's tensor was left alone
+
+
+# -- two processes, one GPU, row tiles ---------------------------------------------------------------
+def test_two_ranks_share_one_gpu_tiles(rt, tmp_path):
+    """Two processes (gloo), each with its own context on cuda:0, render the interleaved row tiles of
+    one frame through sharding.TileShardedFrame and gather them on rank 0: equal to the frame one
+    process renders."""
+    out = str(tmp_path / "frame.npy")
+    worker = os.path.join(ROOT, "tests", "mp_tile_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + os.getpid() % 2000), WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, worker, out], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    logs = [p.communicate(timeout=110)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    got = np.load(out)
+    import mp_tile_worker
+    with rt.RayTracer(mp_tile_worker.W, mp_tile_worker.H) as g:
+        mp_tile_worker.scene_setup(g)
+        g.render(mp_tile_worker.PASSES)
+        assert np.array_equal(got, g.read_pixels())

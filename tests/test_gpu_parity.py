@@ -20,8 +20,8 @@ GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.n
 f32 = np.float32
 
 
-def make_pair(rt, oracle_mod, w, h, threads=8):
-    return rt.RayTracer(w, h), oracle_mod.Oracle(w, h, threads=threads)
+def make_pair(rt, oracle_mod, w, h, threads=8, options=None):
+    return rt.RayTracer(w, h, options=options), oracle_mod.Oracle(w, h, threads=threads)
 
 
 def assert_same(tag, gpu, cpu):
@@ -289,20 +289,19 @@ def test_full_size_filtered_equals_exact_and_is_idempotent(rt):
         assert (pix_a.reshape(-1, 4) != [26, 26, 26, 255]).any(axis=1).mean() > 0.05
 
 
-@pytest.mark.parametrize("grid_bits", ["8", "0"], ids=["direction_cells", "streaming_kernels"])
-def test_sorted_ray_paths_against_oracle(rt, oracle_mod, monkeypatch, grid_bits):
+@pytest.mark.parametrize("grid_bits", [8, 0], ids=["direction_cells", "streaming_kernels"])
+def test_sorted_ray_paths_against_oracle(rt, oracle_mod, grid_bits):
     """The clustered mode's sorted-ray kernels (bounce rays sorted by direction for the band sweep,
     shadow rays sorted by the direction in which they leave the light) normally start at 131072 rays
-    per launch; RT_SORT_MIN_RAYS lowers that so that a frame the oracle can do exercises them:
+    per launch; RT_OPT_SORT_MIN_RAYS lowers that so that a frame the oracle can do exercises them:
     512 x 288 rays, 8 400 triangles, three passes."""
     from opengl_raytracer_amd import scenes
-    monkeypatch.setenv("RT_SORT_MIN_RAYS", "4096")
-    monkeypatch.setenv("RT_GRID_BITS", grid_bits)   # 0: no direction cells, the streaming kernels take over
+    opts = {"sort_min_rays": 4096, "grid_bits": grid_bits}  # 0: no direction cells, the streaming kernels take over
     w, h = 512, 288
     mesh = scenes.concat_meshes(scenes.triangle_soup(8000, seed=99, extent=1.0, size=0.08),
                                 scenes.quad_grid(10, 20, origin=(-1.5, -1.2, 1.2), du=(3.0, 0.0, 0.0), dv=(0.0, 2.4, 0.3)))
     cam = scenes.look_at_camera((0.2, 0.1, -2.6), (0.0, 0.0, 0.0))
-    g, c = make_pair(rt, oracle_mod, w, h, threads=16)
+    g, c = make_pair(rt, oracle_mod, w, h, threads=16, options=opts)
     with g:
         for o in (g, c):
             o.set_mesh(mesh)
@@ -317,11 +316,11 @@ def test_sorted_ray_paths_against_oracle(rt, oracle_mod, monkeypatch, grid_bits)
         # the bounce passes ran as two kernels: band sweep (over direction cells, or streaming with 4 rays
         # per lane), then sphere sweep
         forms = [(int(r["form"]), int(r["rays_per_lane"])) for r in log if int(r["stage"]) == 1]
-        if grid_bits == "0":
+        if grid_bits == 0:
             assert forms[0] == (1, 4) and (2, 4) in forms and (2, 1) in forms, forms
         else:
             # one record per bounce pass when the two sweeps run side by side on two streams (the default),
-            # two when they run in turn (RT_SWEEPS_IN_TURN=1)
+            # two when they run in turn (RT_OPT_SWEEPS_IN_TURN)
             assert forms in ([(3, 1), (2, 1), (2, 1)], [(3, 1), (2, 1), (2, 1), (2, 1), (2, 1)]), forms
 
 
@@ -365,7 +364,7 @@ def test_stage_timers_and_counters(rt):
         log = g.kernel_log()
         # fresh rays share the camera origin (direction cells), shadow rays the light; bounce rays: clustered,
         # one record for the band sweep and the sphere sweep running side by side (two records when they run
-        # in turn, RT_SWEEPS_IN_TURN=1: the band sweep's with the pass's pairs, the sphere sweep's with 0)
+        # in turn, RT_OPT_SWEEPS_IN_TURN: the band sweep's with the pass's pairs, the sphere sweep's with 0)
         forms = [(int(r["stage"]), int(r["form"])) for r in log]
         assert forms in ([(1, 3), (2, 3), (1, 2), (2, 3)], [(1, 3), (2, 3), (1, 2), (1, 2), (2, 3)]), forms
         with_pairs = [0, 1, 2, 3] if len(forms) == 4 else [0, 1, 2, 4]
@@ -373,14 +372,13 @@ def test_stage_timers_and_counters(rt):
         assert g.kernel_log().shape[0] == 0
 
 
-def test_clustered_equals_all_pairs_on_random_scenes(rt, monkeypatch):
+def test_clustered_equals_all_pairs_on_random_scenes(rt):
     """Group rejection against the reference arithmetic on every pair, bit for bit after every stage,
     on randomised scenes: triangle sizes from 0.004 to 0.5, grid floors and walls coplanar with many
     rays, lights and cameras inside the geometry, frames large enough for the sorted-ray kernels
     (tools/fuzz_modes.py runs the same comparison over as many seeds as wanted; 324 seeds passed
     when this test was written, 400 more -- seeds 2000-2099 and 3000-3299 -- with the direction cells, seeds 5000-5399 and 7000-7399 at the final builds of the round)."""
     import sys
-    monkeypatch.setenv("RT_SORT_MIN_RAYS", "16384")
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import fuzz_modes
     lines = []
@@ -400,18 +398,17 @@ def test_per_pair_filters_equal_all_pairs_on_random_scenes(rt):
 
 
 # -- direction cells ---------------------------------------------------------------------------
-@pytest.mark.parametrize("grid_bits", ["4", "7", "10"])
-def test_direction_cells_at_other_resolutions(rt, oracle_mod, monkeypatch, grid_bits):
+@pytest.mark.parametrize("grid_bits", [4, 7, 10])
+def test_direction_cells_at_other_resolutions(rt, oracle_mod, grid_bits):
     """The per-cell triangle lists at the coarsest, a middle and the finest grid (the default, 9 bits per
     axis, is what every other test runs): a camera inside the soup, two lights, three passes."""
     from opengl_raytracer_amd import scenes
-    monkeypatch.setenv("RT_GRID_BITS", grid_bits)
-    monkeypatch.setenv("RT_SORT_MIN_RAYS", "4096")
+    opts = {"grid_bits": grid_bits, "sort_min_rays": 4096}
     w, h = 256, 160
     mesh = scenes.concat_meshes(scenes.triangle_soup(6000, seed=7, extent=1.0, size=0.1),
                                 scenes.quad_grid(8, 8, origin=(-1.5, -1.1, -1.5), du=(3.0, 0.0, 0.0), dv=(0.0, 0.0, 3.0)))
     cam = scenes.look_at_camera((0.1, 0.0, -0.4), (0.0, 0.1, 0.6))
-    g, c = make_pair(rt, oracle_mod, w, h, threads=16)
+    g, c = make_pair(rt, oracle_mod, w, h, threads=16, options=opts)
     with g:
         for o in (g, c):
             o.set_mesh(mesh)

@@ -60,13 +60,12 @@ def test_reference_scenes_against_oracle(rt, oracle_mod, host, name, w, h, passe
         assert (g.read_pixels()[..., :3] != grey).any(-1).mean() > 0.1  # the scene is in the frame
 
 
-def test_small_mesh_default_threshold(rt, oracle_mod, host, monkeypatch):
-    """Without RT_CLUSTER_MIN_TRIS (the other tests run with 0) the bounce rays of the 165-triangle
-    sword go through the per-pair filter (form 0 in the kernel log): same bits as the oracle."""
-    monkeypatch.delenv("RT_CLUSTER_MIN_TRIS", raising=False)
+def test_small_mesh_default_threshold(rt, oracle_mod, host):
+    """With the library's own threshold (1024 triangles; the other tests run with 0) the bounce rays of
+    the 165-triangle sword go through the per-pair filter (form 0 in the kernel log): same bits as the oracle."""
     mesh, tex, cam = scene(host, "sword")
     w, h = 160, 160
-    g, c = rt.RayTracer(w, h), oracle_mod.Oracle(w, h, threads=16)
+    g, c = rt.RayTracer(w, h, options={"cluster_min_tris": 1024}), oracle_mod.Oracle(w, h, threads=16)
     with g:
         for o in (g, c):
             o.set_mesh(mesh); o.set_texture(tex); o.set_lights(host.default_lights(), 2); o.set_camera(*cam)

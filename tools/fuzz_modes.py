@@ -12,7 +12,6 @@ import numpy as np
 
 sys.path.insert(0, os.getcwd())
 sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
-os.environ.setdefault("RT_SORT_MIN_RAYS", "16384")
 import opengl_raytracer_amd as rt
 from opengl_raytracer_amd import scenes
 from common import describe_mismatch, rays_equal_bits
@@ -48,7 +47,7 @@ def run(first, count, log=print, mode=None):
     for seed in range(first, first + count):
         mesh, cam, lights, nl, w, h, passes = scene(seed)
         out = {}
-        with rt.RayTracer(w, h) as g:
+        with rt.RayTracer(w, h, options={"sort_min_rays": 16384, "cluster_min_tris": 0}) as g:
             g.set_mesh(mesh); g.set_texture(scenes.noise_texture(64, 64)); g.set_lights(lights, nl); g.set_camera(*cam)
             for m in (mode, rt.RT_TRACE_EXACT):
                 g.set_trace_mode(m)
