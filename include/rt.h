@@ -182,6 +182,15 @@ int rt_sync(rt_ctx *ctx);
 int rt_read_rays(rt_ctx *ctx, rt_ray *out);
 int rt_write_rays(rt_ctx *ctx, const rt_ray *in);
 
+/* rt_read_rays for callers that cannot allocate device memory (code between graph captures, tight
+ * serving loops, harnesses that forbid hipMalloc): the same records, but the device-side staging of
+ * the 80-byte layout lives in a static 64 MiB device array instead of a buffer allocated per call.
+ * No counterpart in the reference.  At most 838 860 rays (64 MiB / 80 bytes; RT_ERR_ARG beyond:
+ * shrink the context's share with rt_set_row_tiles or use rt_read_rays).  The array is one per GPU and
+ * shared by every context on it: calls that overlap on one GPU race.  Synchronises; makes no
+ * hipMalloc / hipFree call. */
+int rt_read_rays_static(rt_ctx *ctx, rt_ray *out);
+
 /* Local framebuffer (rt_local_rows() x width x RGBA8, row 0 = lowest y) and the
  * depth plane rayintersect_cs.glsl:29-31 writes (distance(origin, camera_pos),
  * kept as float32; 0 where intersect has not written).  Both synchronise. */

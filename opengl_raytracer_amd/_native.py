@@ -64,6 +64,7 @@ PROTOTYPES = {
     "rt_render": (C.c_int, [_P, C.c_int]),
     "rt_sync": (C.c_int, [_P]),
     "rt_read_rays": (C.c_int, [_P, _P]),
+    "rt_read_rays_static": (C.c_int, [_P, _P]),
     "rt_write_rays": (C.c_int, [_P, _P]),
     "rt_read_pixels_rgba8": (C.c_int, [_P, _P]),
     "rt_read_depth": (C.c_int, [_P, _P]),

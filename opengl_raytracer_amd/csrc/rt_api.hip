@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -24,6 +25,34 @@
 using namespace rtk;
 
 static thread_local std::string g_create_error;
+
+// Staging memory of rt_read_rays_static: the 80-byte records are assembled here before they are copied
+// to the host.  Every GPU the library runs on holds its own copy of the array, at its own address, until
+// the process ends.  In host code the array's name is only a handle for hipGetSymbolAddress: the address
+// that kernels and copies take is looked up once per device (rt_create, with that device current) and
+// kept in g_static_stage_ptr.
+constexpr size_t STATIC_STAGE_BYTES = (size_t)64 << 20;
+constexpr size_t STATIC_STAGE_MAX_RAYS = STATIC_STAGE_BYTES / sizeof(rt_ray);
+static __device__ __align__(256) unsigned char g_static_stage[STATIC_STAGE_BYTES];
+constexpr int STATIC_STAGE_MAX_DEVICES = 64;
+static void *g_static_stage_ptr[STATIC_STAGE_MAX_DEVICES] = {};
+static std::mutex g_static_stage_mutex;
+
+// device address of g_static_stage on the current device `dev` (looked up on first use)
+static hipError_t static_stage_address(int dev, void **out)
+{
+    if (dev < 0 || dev >= STATIC_STAGE_MAX_DEVICES) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_static_stage_mutex);
+    if (!g_static_stage_ptr[dev]) {
+        void *ptr = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_static_stage));
+        if (e != hipSuccess) return e;
+        if (!ptr) return hipErrorInvalidSymbol;
+        g_static_stage_ptr[dev] = ptr;
+    }
+    *out = g_static_stage_ptr[dev];
+    return hipSuccess;
+}
 
 struct EventPair {
     hipEvent_t a, b;
@@ -124,6 +153,8 @@ struct rt_ctx {
     float *work = nullptr;  // per-slot planes behind job / scratch
     Job job{};
     Scratch scratch{};
+
+    void *static_stage = nullptr; // this device's copy of g_static_stage (rt_read_rays_static)
 
     uint32_t *fb_own = nullptr;
     uint32_t *fb = nullptr;
@@ -302,6 +333,7 @@ extern "C" int rt_create(rt_ctx **out, int hip_device, int width, int height)
         }                                                                                      \
     } while (0)
     CRCHK(hipSetDevice(hip_device));
+    CRCHK(static_stage_address(hip_device, &c->static_stage));
     CRCHK(hipStreamCreateWithFlags(&c->stream_own, hipStreamNonBlocking));
     CRCHK(hipStreamCreateWithFlags(&c->stream_side, hipStreamNonBlocking));
     CRCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -1515,6 +1547,25 @@ extern "C" int rt_read_rays(rt_ctx *c, rt_ray *out)
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(tmp);
     if (e != hipSuccess) return fail(c, RT_ERR_HIP, "rt_read_rays: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
+// rt_read_rays without an allocation: the records are assembled in the device's static staging array.
+extern "C" int rt_read_rays_static(rt_ctx *c, rt_ray *out)
+{
+    if (!c || !out) return RT_ERR_ARG;
+    if (int r = use_device(c)) return r;
+    if (c->n_rays == 0) return RT_OK;
+    if ((size_t)c->n_rays > STATIC_STAGE_MAX_RAYS)
+        return fail(c, RT_ERR_ARG, "rt_read_rays_static: %d rays exceed the static staging array (%zu rays of 80 bytes, "
+                    "%zu MiB); use rt_read_rays or rt_set_row_tiles", c->n_rays, STATIC_STAGE_MAX_RAYS,
+                    STATIC_STAGE_BYTES >> 20);
+    rt_ray *stage = reinterpret_cast<rt_ray *>(c->static_stage);
+    hipLaunchKernelGGL(soa_to_aos_kernel, dim3(cdiv(c->n_rays, BLOCK)), dim3(BLOCK), 0, c->stream, c->rays, c->n_rays,
+                       stage);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out, stage, (size_t)c->n_rays * sizeof(rt_ray), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return RT_OK;
 }
 

@@ -127,6 +127,12 @@ class RayTracer:
         self._chk(self._lib.rt_read_rays(self._ctx, out.ctypes.data))
         return out
 
+    def read_rays_static(self):
+        """read_rays through the static staging array (no device allocation; at most 838 860 rays)."""
+        out = np.empty(self.num_rays, dtype=RAY_DTYPE)
+        self._chk(self._lib.rt_read_rays_static(self._ctx, out.ctypes.data))
+        return out
+
     def write_rays(self, rays):
         r = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
         assert r.shape[0] == self.num_rays
