@@ -149,14 +149,17 @@ int rt_set_trace_mode(rt_ctx *ctx, int mode /* rt_trace_mode */);
  *   RT_OPT_BAND_LIST_MAX    the band sweep's per-cell lists are built only if they hold at most this
  *                           many entries in total (default and maximum 0xffffff00: list positions
  *                           are 32-bit); beyond it the streaming band sweep runs
- * RT_OPT_GRID_BITS and RT_OPT_BAND_LIST_MAX decide what rt_set_mesh builds: after setting one of them
- * the context has no mesh until the next rt_set_mesh. */
+ *   RT_OPT_VOXEL_RES        cells along the longest axis of the grid in space that bounce rays walk,
+ *                           1..128, or 0 = chosen from the number of triangles (default 0)
+ * RT_OPT_GRID_BITS, RT_OPT_BAND_LIST_MAX and RT_OPT_VOXEL_RES decide what rt_set_mesh builds: after
+ * setting one of them the context has no mesh until the next rt_set_mesh. */
 typedef enum rt_option {
     RT_OPT_SORT_MIN_RAYS    = 0,
     RT_OPT_CLUSTER_MIN_TRIS = 1,
     RT_OPT_GRID_BITS        = 2,
     RT_OPT_SWEEPS_IN_TURN   = 3,
-    RT_OPT_BAND_LIST_MAX    = 4
+    RT_OPT_BAND_LIST_MAX    = 4,
+    RT_OPT_VOXEL_RES        = 5
 } rt_option;
 int rt_set_option(rt_ctx *ctx, int option /* rt_option */, long long value);
 

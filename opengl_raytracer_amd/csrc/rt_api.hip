@@ -21,6 +21,7 @@
 #include "../../include/rt.h"
 #include "rt_kernels.h"
 #include "rt_cluster.h"
+#include "rt_voxel.h"
 
 using namespace rtk;
 
@@ -96,10 +97,11 @@ struct rt_ctx {
     float4 *nsub_d = nullptr;
     float4 *nrec_d = nullptr;
     int num_ngroups = 0;
-    float4 *sphere_d = nullptr;
-    rtf::TriRec *crec_d = nullptr;
-    int *member_d = nullptr;
-    int num_clusters = 0;
+    // cells in space for the well-conditioned pairs of arbitrary rays (rt_voxel.h)
+    rtv::Grid vox{};
+    unsigned int *vox_off_d = nullptr;
+    int *vox_entries_d = nullptr;
+    int voxel_res = 0; // cells along the longest axis; 0: chosen from the number of triangles
     bool camera_recs_dirty = true;
     bool light_recs_dirty = true;
     // direction cells (rt_grid.h): per shared origin (0 = camera, 1 + a = light a) the list offsets
@@ -443,9 +445,8 @@ extern "C" void rt_destroy(rt_ctx *c)
     (void)hipFree(c->ngroup_d);
     (void)hipFree(c->nsub_d);
     (void)hipFree(c->nrec_d);
-    (void)hipFree(c->sphere_d);
-    (void)hipFree(c->crec_d);
-    (void)hipFree(c->member_d);
+    (void)hipFree(c->vox_off_d);
+    (void)hipFree(c->vox_entries_d);
     (void)hipFree(c->tex);
     (void)hipFree(c->list);
     (void)hipFree(c->alist[0]);
@@ -511,7 +512,7 @@ static int build_band_cells(rt_ctx *c)
                        c->grid_count_d, (const unsigned int *)nullptr, (int *)nullptr);
     HIPCHK(c, hipGetLastError());
     // List positions are 32-bit: the exact total decides.  Longer lists are not built, and the streaming
-    // band sweep (traverse_band_kernel / traverse_cluster_kernel) takes over.
+    // band sweep (traverse_band_kernel / traverse_group_kernel) takes over.
     unsigned long long total64 = 0;
     if (int r = sum_counts(c, c->grid_count_d, ncells + 2, &total64)) return r;
     if (total64 > c->band_list_max) {
@@ -558,15 +559,13 @@ extern "C" int rt_set_mesh(rt_ctx *c, const rt_vertex *vertices, int num_vertice
     (void)hipFree(c->nsub_d); c->nsub_d = nullptr;
     (void)hipFree(c->nrec_d); c->nrec_d = nullptr;
     c->num_ngroups = 0;
-    (void)hipFree(c->sphere_d); c->sphere_d = nullptr;
-    (void)hipFree(c->crec_d); c->crec_d = nullptr;
-    (void)hipFree(c->member_d); c->member_d = nullptr;
+    (void)hipFree(c->vox_off_d); c->vox_off_d = nullptr;
+    (void)hipFree(c->vox_entries_d); c->vox_entries_d = nullptr;
     (void)hipFree(c->band_off); c->band_off = nullptr;
     (void)hipFree(c->band_entries); c->band_entries = nullptr;
     (void)hipFree(c->slot_views_d); c->slot_views_d = nullptr;
     (void)hipFree(c->build_work_d); c->build_work_d = nullptr;
     (void)hipFree(c->build_item_d); c->build_item_d = nullptr;
-    c->num_clusters = 0;
     c->num_vertices = num_vertices;
     c->num_tris = num_vertices / 3;
     // record arrays are padded to whole tiles so that a tile copy never leaves the allocation
@@ -627,9 +626,8 @@ extern "C" int rt_set_mesh(rt_ctx *c, const rt_vertex *vertices, int num_vertice
         // plane bands and clusters for the clustered traversal (needs the bounding sphere)
         rtc::ClusterSet cs;
         rtc::build(vertices, c->num_tris, c->center, c->radius, cs);
-        c->num_clusters = cs.num_clusters;
         c->num_ngroups = cs.num_ngroups;
-        const size_t ng = (size_t)cs.num_ngroups, nc = (size_t)cs.num_clusters;
+        const size_t ng = (size_t)cs.num_ngroups;
         // the shared-origin traversal's records live in slot order (a whole number of 1024-slot tiles)
         c->num_slots = (int)cs.slots.size();
         c->rec_stride = (size_t)c->num_slots + CONE_TILE;
@@ -649,9 +647,6 @@ extern "C" int rt_set_mesh(rt_ctx *c, const rt_vertex *vertices, int num_vertice
         HIPCHK(c, hipMalloc(&c->ngroup_d, (ng + 1) * sizeof(float4)));
         HIPCHK(c, hipMalloc(&c->nsub_d, (ng * (rtc::NGROUP / rtc::SUBGROUP) + 1) * sizeof(float4)));
         HIPCHK(c, hipMalloc(&c->nrec_d, (ng * rtc::NGROUP + 1) * 2 * sizeof(float4)));
-        HIPCHK(c, hipMalloc(&c->sphere_d, (nc + 1) * sizeof(float4)));
-        HIPCHK(c, hipMalloc(&c->crec_d, (nc * rtc::CLUSTER + 1) * sizeof(rtf::TriRec)));
-        HIPCHK(c, hipMalloc(&c->member_d, (nc * rtc::CLUSTER + 1) * sizeof(int)));
         if (ng) {
             HIPCHK(c, hipMemcpyAsync(c->ngroup_d, cs.ngroups.data(), ng * sizeof(float4), hipMemcpyHostToDevice, c->stream));
             HIPCHK(c, hipMemcpyAsync(c->nsub_d, cs.nsubs.data(), ng * (rtc::NGROUP / rtc::SUBGROUP) * sizeof(float4),
@@ -659,12 +654,21 @@ extern "C" int rt_set_mesh(rt_ctx *c, const rt_vertex *vertices, int num_vertice
             HIPCHK(c, hipMemcpyAsync(c->nrec_d, cs.nrecs.data(), ng * rtc::NGROUP * 2 * sizeof(float4),
                                      hipMemcpyHostToDevice, c->stream));
         }
-        if (nc) {
-            HIPCHK(c, hipMemcpyAsync(c->sphere_d, cs.spheres.data(), nc * sizeof(float4), hipMemcpyHostToDevice, c->stream));
-            HIPCHK(c, hipMemcpyAsync(c->crec_d, cs.recs.data(), nc * rtc::CLUSTER * sizeof(rtf::TriRec),
+        {
+            // the cells in space: the triangles the band records leave to the spatial sweep (rho >= 0)
+            rtv::VoxelSet vs;
+            const double abs_extent = std::sqrt((double)c->center[0] * c->center[0] + (double)c->center[1] * c->center[1] +
+                                                (double)c->center[2] * c->center[2]) + 3.0 * (double)c->radius;
+            rtv::build(vertices, c->num_tris, cs.rho, abs_extent, c->voxel_res, vs);
+            c->vox = vs.grid;
+            HIPCHK(c, hipMalloc(&c->vox_off_d, vs.off.size() * sizeof(unsigned int)));
+            HIPCHK(c, hipMalloc(&c->vox_entries_d, (vs.entries.size() + 1) * sizeof(int)));
+            HIPCHK(c, hipMemcpyAsync(c->vox_off_d, vs.off.data(), vs.off.size() * sizeof(unsigned int),
                                      hipMemcpyHostToDevice, c->stream));
-            HIPCHK(c, hipMemcpyAsync(c->member_d, cs.members.data(), nc * rtc::CLUSTER * sizeof(int),
-                                     hipMemcpyHostToDevice, c->stream));
+            if (!vs.entries.empty())
+                HIPCHK(c, hipMemcpyAsync(c->vox_entries_d, vs.entries.data(), vs.entries.size() * sizeof(int),
+                                         hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream)); // vs goes out of scope
         }
         HIPCHK(c, hipStreamSynchronize(c->stream)); // the host vectors go out of scope
         if (int r = build_band_cells(c)) return r;
@@ -787,6 +791,11 @@ extern "C" int rt_set_option(rt_ctx *c, int option, long long value)
         c->band_list_max = (unsigned long long)value;
         c->have_mesh = false; // the lists are built by rt_set_mesh
         return RT_OK;
+    case RT_OPT_VOXEL_RES:
+        if (value < 0 || value > 128) break;
+        c->voxel_res = (int)value;
+        c->have_mesh = false; // the cells are built by rt_set_mesh
+        return RT_OK;
     case RT_OPT_GRID_BITS: {
         if (!(value == 0 || (value >= 4 && value <= rtg::MAX_BITS))) break;
         if (int r = use_device(c)) return r;
@@ -891,13 +900,9 @@ static int pick_rays_per_lane(int n)
 
 // splits `tiles` LDS tiles over blockIdx.y so that the launch has at least ~2048
 // workgroups (8 per CU): short launches then fill the chip and end together.
-static int pick_tiles_per_y(int ray_blocks, int tiles, bool sphere_sweep = false)
+static int pick_tiles_per_y(int ray_blocks, int tiles)
 {
-    const int target_stream = 8192;
-    // the sphere sweep's workgroups differ a lot in length (their rays pass different numbers of clusters):
-    // four times as many, shorter ones even out the end of the launch (2.18 -> 2.02 ms per pass at 0.8 M rays)
-    const int target_sphere = 32768;
-    const int target = sphere_sweep ? target_sphere : target_stream;
+    const int target = 8192;
     int want_y = (target + ray_blocks - 1) / ray_blocks;
     if (want_y < 1) want_y = 1;
     if (want_y > tiles) want_y = tiles;
@@ -987,90 +992,68 @@ static int launch_traverse_clustered(rt_ctx *c, TraverseParams p, int n_upper, b
     p.nsubs = c->nsub_d;
     p.nrecs = c->nrec_d;
     p.num_ngroups = c->num_ngroups;
-    p.spheres = c->sphere_d;
-    p.crecs = c->crec_d;
-    p.members = c->member_d;
-    p.num_clusters = c->num_clusters;
-    const int tiles = cdiv(p.tri_end - p.tri_begin, TILE);
-    if (n_upper <= 0 || tiles <= 0) return RT_OK;
+    p.vox = c->vox;
+    p.vox_off = c->vox_off_d;
+    p.vox_entries = c->vox_entries_d;
+    if (n_upper <= 0 || p.tri_end <= p.tri_begin) return RT_OK;
+    const unsigned long long pairs = (unsigned long long)n_upper * (unsigned long long)(p.tri_end - p.tri_begin);
     size_t ks;
-    // With the band lists the two sweeps are two kernels that only meet in `best` (atomicMin): they run
-    // side by side, the sphere sweep on the side stream, and the log holds one record for the pair.
+    // The two sweeps are two kernels that only meet in `best` (atomicMin).  With the band lists they run
+    // side by side, the walk over the cells in space on the side stream, and the log holds one record for
+    // the pair; otherwise one after the other, one record each (the second with 0 pairs).
     const bool fork = c->band_entries && sweeps_side_by_side(c);
+    if (fork) {
+        // rt_intersect forks before it sorts the rays for the band sweep (the walk does not wait for the sort)
+        if (c->forked) ks = c->forked_ks;
+        else if (int r = fork_side_stream(c, n_upper, &ks)) return r;
+        c->forked = false;
+    } else if (int r = klog_begin(c, 1, 2, 1, false, (unsigned long long)n_upper, pairs, &ks)) {
+        return r;
+    }
+    // ---- the band sweep: ill-conditioned pairs
+    TraverseParams a = p;
+    if (sorted) {
+        // sorted rays share direction cells / groups; any order gives the same result
+        a.alist = c->sort_slots;
+        a.count = nullptr;
+        a.n = n_upper;
+    }
     if (c->band_entries) {
-        // sweep A over the direction cells (sorted rays share cells, any order gives the same result),
-        // sweep B beside it (or after it)
-        TraverseParams a = p;
-        a.alist = sorted ? c->sort_slots : nullptr;
-        if (sorted) { a.count = nullptr; a.n = n_upper; }
         a.band_off = c->band_off;
         a.band_entries = c->band_entries;
         a.grid_bits = c->grid_bits;
-        if (fork) {
-            // rt_intersect forks before it sorts the rays for the band sweep (the sphere sweep does not wait
-            // for the sort)
-            if (c->forked) ks = c->forked_ks;
-            else if (int r = fork_side_stream(c, n_upper, &ks)) return r;
-            c->forked = false;
-        } else if (int r = klog_begin(c, 1, 2, 1, false, (unsigned long long)n_upper,
-                                      (unsigned long long)n_upper * (unsigned long long)(p.tri_end - p.tri_begin), &ks)) {
-            return r;
-        }
         a.rays_per_wave = pick_rays_per_wave(n_upper);
         hipLaunchKernelGGL(traverse_bandcell_kernel, dim3(cdiv(n_upper, (BLOCK / 64) * a.rays_per_wave)), dim3(BLOCK), 0,
                            c->stream, a);
-        HIPCHK(c, hipGetLastError());
-        if (!fork)
-            if (int r = klog_end(c, ks)) return r;
-        p.sweeps = 2;
     } else if (sorted) {
-        {
-            TraverseParams a = p;
-            a.alist = c->sort_slots;
-            a.count = nullptr;
-            a.n = n_upper;
-            const int k = 4;
-            const int ray_blocks = cdiv(n_upper, BLOCK * k);
-            const int band_target = 8192;
-            int want_y = (band_target + ray_blocks - 1) / ray_blocks;
-            const int max_y = cdiv(c->num_ngroups, BAND_TILE_GROUPS);
-            if (want_y > max_y) want_y = max_y;
-            if (want_y < 1) want_y = 1;
-            if (int r = klog_begin(c, 1, 2, k, false, (unsigned long long)n_upper,
-                                   (unsigned long long)n_upper * (unsigned long long)(p.tri_end - p.tri_begin), &ks))
-                return r;
-            hipLaunchKernelGGL((traverse_band_kernel<4>), dim3(ray_blocks, want_y), dim3(BLOCK), 0, c->stream, a);
-            HIPCHK(c, hipGetLastError());
-            if (int r = klog_end(c, ks)) return r;
-        }
-        p.sweeps = 2;
+        const int ray_blocks = cdiv(n_upper, BLOCK * 4);
+        int want_y = (8192 + ray_blocks - 1) / ray_blocks;
+        const int max_y = cdiv(c->num_ngroups, BAND_TILE_GROUPS);
+        if (want_y > max_y) want_y = max_y;
+        if (want_y < 1) want_y = 1;
+        hipLaunchKernelGGL((traverse_band_kernel<4>), dim3(ray_blocks, want_y), dim3(BLOCK), 0, c->stream, a);
     } else {
-        p.sweeps = 3;
-    }
-    // 32 (sphere sweep only) or 48 bytes of LDS per staged ray; one ray per lane keeps seven
-    // workgroups on a CU, which hides the latency of the member loops better than two rays per
-    // lane save sphere-test overhead
-    const int k = 1;
-    const int ray_blocks = cdiv(n_upper, BLOCK * k);
-    p.tiles_per_y = pick_tiles_per_y(ray_blocks, tiles, true);
-    p.tiles_per_y = (p.tiles_per_y + CONE_TILE / TILE - 1) / (CONE_TILE / TILE) * (CONE_TILE / TILE);
-    const dim3 grid(ray_blocks, cdiv(tiles, p.tiles_per_y));
-    if (!fork)
-        if (int r = klog_begin(c, 1, 2, k, false, (unsigned long long)n_upper,
-                               p.sweeps == 2 ? 0ull : (unsigned long long)n_upper * (unsigned long long)(p.tri_end - p.tri_begin), &ks))
-            return r;
-    if (p.sweeps == 2) {
-        hipStream_t st = fork ? c->stream_side : c->stream;
-        hipLaunchKernelGGL((traverse_cluster_kernel<1, 2>), grid, dim3(BLOCK), 0, st, p);
-        if (fork) {
-            HIPCHK(c, hipGetLastError());
-            HIPCHK(c, hipEventRecord(c->ev_join, c->stream_side));
-            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
-        }
-    } else {
-        hipLaunchKernelGGL((traverse_cluster_kernel<1, 3>), grid, dim3(BLOCK), 0, c->stream, p);
+        const int ray_blocks = cdiv(n_upper, BLOCK);
+        int want_y = (8192 + ray_blocks - 1) / ray_blocks;
+        const int max_y = cdiv(c->num_ngroups, GROUP_TILE);
+        if (want_y > max_y) want_y = max_y;
+        if (want_y < 1) want_y = 1;
+        hipLaunchKernelGGL(traverse_group_kernel, dim3(ray_blocks, want_y), dim3(BLOCK), 0, c->stream, a);
     }
     HIPCHK(c, hipGetLastError());
+    if (!fork) {
+        if (int r = klog_end(c, ks)) return r;
+        if (int r = klog_begin(c, 1, 2, 1, false, (unsigned long long)n_upper, 0ull, &ks)) return r;
+    }
+    // ---- the walk over the cells in space: well-conditioned pairs (rays in pixel-tile order: neighbours
+    //      start in the same cells)
+    hipLaunchKernelGGL(traverse_voxel_kernel, dim3(cdiv(n_upper, BLOCK)), dim3(BLOCK), 0,
+                       fork ? c->stream_side : c->stream, p);
+    HIPCHK(c, hipGetLastError());
+    if (fork) {
+        HIPCHK(c, hipEventRecord(c->ev_join, c->stream_side));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    }
     return klog_end(c, ks);
 }
 

@@ -1,7 +1,7 @@
-// rt_cluster.h -- host-side construction of the band records and triangle clusters that the
-// clustered traversal of arbitrary rays reads (theory: rt_filter.h, "Plane-band test and cluster
-// spheres").  Triangles are split by medians of their centroids (a k-d tree cut off at leaves of
-// CLUSTER triangles); each leaf gets a sphere that contains its triangles grown by their rho.
+// rt_cluster.h -- host-side construction of the band records that the clustered traversal of
+// arbitrary rays reads (theory: rt_filter.h, "Plane-band test") and of the order in which the
+// shared-origin traversal visits the triangles.  Triangles are split by medians of their centroids
+// (a k-d tree cut off at leaves of CLUSTER triangles): neighbours in space sit in neighbouring slots.
 // A second split, by the direction of the normal, gives the groups of the band sweep.
 // Host code only (rt_api.hip and the filter model test).
 #pragma once
@@ -27,9 +27,7 @@ struct ClusterSet {
     double origin_limit = 0.0;           // ... which is every ray with |o - centre| <= origin_limit
     std::vector<rtf::BandRec> bands;     // one per triangle, mesh order
     std::vector<rtf::SlabRec> slabs;     // one per triangle, mesh order
-    std::vector<float> spheres;          // 4 per cluster: centre, R^2 (rounded up)
     std::vector<int32_t> members;        // CLUSTER per cluster: triangle index or -1
-    std::vector<rtf::TriRec> recs;       // CLUSTER per cluster: general edge record of the member
     int num_clusters = 0;
     // triangles grouped by the direction of their normal: a ray's direction is in the band of a
     // member only if it is in the group's band (axis, w): |axis . b| < w
@@ -48,6 +46,10 @@ struct ClusterSet {
     // 1024-record tiles.  Every triangle appears exactly once.
     std::vector<int32_t> slots;
     int num_ngroups = 0;
+    // per triangle, mesh order: rho (rt_filter.h) of the triangles that sit in clusters -- the ones whose
+    // well-conditioned pairs a spatial structure must find -- and -1 for the others (never accepted,
+    // or always in the band)
+    std::vector<double> rho;
 };
 
 constexpr int NGROUP = 64;
@@ -92,9 +94,7 @@ inline void build(const rt_vertex *v, int num_tris, const float center[3], float
     out.slabs.assign((size_t)num_tris, rtf::SlabRec{{0.0f, INFINITY}});
     const double abs_extent = std::sqrt((double)center[0] * center[0] + (double)center[1] * center[1] +
                                         (double)center[2] * center[2]) + 3.0 * (double)radius;
-    out.spheres.clear();
     out.members.clear();
-    out.recs.clear();
     out.num_clusters = 0;
 
     std::vector<double> rho((size_t)num_tris, -1.0);
@@ -131,53 +131,15 @@ inline void build(const rt_vertex *v, int num_tris, const float center[3], float
         rho[t] = r;
     }
 
+    out.rho = rho;
     kd_order(regular, 0, regular.size(), CLUSTER, [&](int32_t t) { return &cen[(size_t)t * 3]; });
     // one more split inside every leaf: the shared-origin traversal skips runs of RUN slots
     for (size_t b = 0; b < regular.size(); b += CLUSTER)
         kd_order(regular, b, std::min(regular.size(), b + CLUSTER), RUN, [&](int32_t t) { return &cen[(size_t)t * 3]; });
     const std::vector<int32_t> &keyed = regular;
     out.num_clusters = (int)((keyed.size() + CLUSTER - 1) / CLUSTER);
-    out.spheres.assign((size_t)out.num_clusters * 4, 0.0f);
     out.members.assign((size_t)out.num_clusters * CLUSTER, -1);
-    out.recs.resize((size_t)out.num_clusters * CLUSTER);
-    for (auto &r : out.recs) rtf::nan_rec(&r);
-    for (int c = 0; c < out.num_clusters; c++) {
-        const size_t b = (size_t)c * CLUSTER, e = std::min(keyed.size(), b + CLUSTER);
-        double blo[3], bhi[3];
-        for (size_t i = b; i < e; i++) {
-            const int t = keyed[i];
-            for (int k = 0; k < 3; k++)
-                for (int a = 0; a < 3; a++) {
-                    const double x = v[3 * t + k].pos[a];
-                    if ((i == b && k == 0) || x < blo[a]) blo[a] = x;
-                    if ((i == b && k == 0) || x > bhi[a]) bhi[a] = x;
-                }
-        }
-        float cf[3];
-        for (int a = 0; a < 3; a++) cf[a] = (float)((blo[a] + bhi[a]) * 0.5);
-        double R = 0.0;
-        for (size_t i = b; i < e; i++) {
-            const int t = keyed[i];
-            out.members[b + (i - b)] = t;
-            rtf::make_general_rec(v[3 * t].pos, v[3 * t + 1].pos, v[3 * t + 2].pos, &out.recs[b + (i - b)]);
-            for (int k = 0; k < 3; k++) {
-                double d2 = 0.0;
-                for (int a = 0; a < 3; a++) {
-                    const double d = (double)v[3 * t + k].pos[a] - (double)cf[a];
-                    d2 += d * d;
-                }
-                R = std::max(R, std::sqrt(d2) + rho[t]);
-            }
-        }
-        const double cl = std::sqrt((double)cf[0] * cf[0] + (double)cf[1] * cf[1] + (double)cf[2] * cf[2]);
-        R = R * (1.0 + 1e-5) + 1e-6 * (cl + R); // float arithmetic on the centre in the kernel
-        float r2 = (float)(R * R);
-        if ((double)r2 < R * R) r2 = std::nextafterf(r2, INFINITY);
-        out.spheres[(size_t)c * 4 + 0] = cf[0];
-        out.spheres[(size_t)c * 4 + 1] = cf[1];
-        out.spheres[(size_t)c * 4 + 2] = cf[2];
-        out.spheres[(size_t)c * 4 + 3] = r2;
-    }
+    for (size_t i = 0; i < keyed.size(); i++) out.members[i] = keyed[i];
     build_normal_groups(out);
 
     // Groups of neighbouring clusters (a SUPER_RUN of slots) are laid out with a large stride

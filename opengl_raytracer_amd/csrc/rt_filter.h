@@ -495,7 +495,7 @@ RT_HD double scene_extent(const float O[3], const float C[3], float R)
 }
 
 // ---------------------------------------------------------------------------
-// Plane-band test and cluster spheres for arbitrary rays.
+// Plane-band test for arbitrary rays, and how far from its triangle a well-conditioned hit can lie.
 //
 // Which pairs can the reference's arithmetic accept?  Write e1, e2 for the float edges it forms,
 // s = o - X, a = e1.(d x e2), Nu = s.(d x e2), Nv = d.(s x e1), and a^, Nu^, Nv^ for what it
@@ -516,8 +516,8 @@ RT_HD double scene_extent(const float O[3], const float C[3], float R)
 //           s.n = (-(s.d) a + Nv (d.e2) + Nu (d.e1)) / |d|^2,    n = e1 x e2,
 //       the ray's origin then lies within  H = theta (S + |e1| + |e2|)  of the triangle's plane.
 // So a pair outside the slab (B) -- direction out of the band, or origin farther than H from the
-// plane -- whose line misses a sphere containing the triangle grown by rho is one the reference
-// rejects.  K = 17: rho = (|e1| + |e2|)/8.
+// plane -- whose line stays farther than rho from the triangle is one the reference rejects (the
+// cells in space of rt_voxel.h are built on that).  K = 17: rho = (|e1| + |e2|)/8.
 //
 // BandRec = (unit normal, theta').  theta' = theta + 2^-20 covers the float dot product with a
 // float-normalised direction.  theta' = +inf: every direction is in the band (slivers, edges
@@ -591,21 +591,6 @@ RT_HD bool band_test(const float *rec, float bx, float by, float bz)
 {
     const float t = fmaf(rec[2], bz, fmaf(rec[1], by, rec[0] * bx));
     return fabsf(t) < rec[3];
-}
-
-// Does the half-line from (ox,oy,oz) along the float-normalised direction (bx,by,bz) pass within
-// the cluster's sphere?  rec = (centre, R^2 rounded up).  The 2^-20 |L|^2 slack covers the
-// cancellation in |L|^2 - (L.b)^2 and |b| != 1.
-RT_HD bool cluster_test(const float *rec, float ox, float oy, float oz, float bx, float by, float bz)
-{
-    const float lx = rec[0] - ox, ly = rec[1] - oy, lz = rec[2] - oz;
-    const float ll = fmaf(lz, lz, fmaf(ly, ly, lx * lx));
-    const float b = fmaf(lz, bz, fmaf(ly, by, lx * bx));
-    const float q = fmaf(-b, b, ll);
-    // behind the origin by more than twice the radius: the reference keeps t > 0 only, and a computed
-    // t > 0 with a well-conditioned determinant puts the true hit point at most rho (< R) behind it
-    if (b < 0.0f && b * b > 4.0f * rec[3]) return false;
-    return fmaf(ll, -9.5367431640625e-07f, q) <= rec[3];
 }
 
 } // namespace rtf

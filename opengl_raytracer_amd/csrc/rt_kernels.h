@@ -19,6 +19,7 @@
 #include "rt_exact.h"
 #include "rt_filter.h"
 #include "rt_grid.h"
+#include "rt_voxel.h"
 
 namespace rtk {
 
@@ -324,7 +325,10 @@ __device__ __forceinline__ void prepare_general(const Job &job, int slot, v3 o, 
     const float g = rtf::dir_scale(dist + 3.0f * radius, d.x, d.y, d.z);
     const float inv = 1.0f / sqrtf(rtx::dot(d, d));
     job.bx[slot] = d.x * inv; job.by[slot] = d.y * inv; job.bz[slot] = d.z * inv;
-    job.g[slot] = (dist <= 1.25f * radius) ? g : -g;
+    // (a direction so short or long that the walk over the cells in space would overflow counts as outside
+    // too: the band sweep then takes every pair of the ray)
+    const float dd = rtx::dot(d, d);
+    job.g[slot] = (dist <= 1.25f * radius && dd > 1e-30f && dd < 1e30f) ? g : -g;
 }
 
 struct SharedOrigin { // the shared origin of a launch and the validity range of its cones
@@ -434,18 +438,17 @@ struct TraverseParams {
     const unsigned int *band_off;
     const int *band_entries;
     int rays_per_wave;            // direction-cell kernels: 64, or fewer for small launches (see their comments)
-    // clustered traversal of arbitrary rays (traverse_cluster_kernel) only
-    int sweeps;                 // host side: which instantiation of traverse_cluster_kernel (bit 0 = sweep A, bit 1 = sweep B)
+    // band sweeps of arbitrary rays (traverse_group_kernel, traverse_band_kernel, traverse_bandcell_kernel)
     const float4 *ngroups;      // one (axis, w) per group of triangles with similar normals
     const float4 *nsubs;        // one (axis, w) per SUBGROUP members of a group (traverse_band_kernel)
     const float4 *nrecs;        // the members, two float4 each: (n/theta, kappa/H), (n/H, triangle index);
                                 // inside the member's band and slab <=> max(|n1.b|, |n2.o - kappa'|) < 1
     int num_ngroups;
-    const float4 *spheres;      // one (centre, R^2) per cluster of triangles close in space
     const rtf::MomRec *mrecs;   // per-pair mode, arbitrary rays: moment-form records in triangle order
-    const rtf::TriRec *crecs;   // the members' general edge records, CLUSTER per cluster
-    const int *members;         // triangle index of each of them, or -1
-    int num_clusters;
+    // cells in space (traverse_voxel_kernel): per cell the triangles that come near it
+    rtv::Grid vox;
+    const unsigned int *vox_off;
+    const int *vox_entries;
 };
 
 // cooperative copy of one tile of the per-pair filter's 64-byte moment records into LDS; records
@@ -509,7 +512,7 @@ __launch_bounds__(BLOCK) void traverse_kernel(TraverseParams p)
     __shared__ float4 lds4[FORM == 1 ? CONE_TILE : TILE * 4];
     __shared__ float4 run4[FORM == 1 ? CONE_TILE / RUN : 1];       // FORM 1: the cones of the tile's runs
     __shared__ float4 sup4[FORM == 1 ? CONE_TILE / SUPER_RUN : 1]; // ... and of the level above
-    constexpr int TSZ = (FORM == 1) ? CONE_TILE : TILE;
+    constexpr int TSZ = (FORM == 1 && !EXACT) ? CONE_TILE : TILE;
 
     const int tid = threadIdx.x;
     const int n = p.count ? *p.count : p.n;
@@ -587,10 +590,8 @@ __launch_bounds__(BLOCK) void traverse_kernel(TraverseParams p)
     const unsigned long long tm_start = __builtin_amdgcn_s_memtime();
 #endif
 
-    // second level (FORM 1) / candidate handling for one triangle; `pass` says which of the
-    // lane's rays go to the reference arithmetic
-    auto exact_stage = [&](int tri, const bool (&pass)[K]) {
-        const v3 X = vpos(p.verts, 3 * tri), Y = vpos(p.verts, 3 * tri + 1), Z = vpos(p.verts, 3 * tri + 2);
+    // the reference arithmetic for one triangle (vertices X, Y, Z); `pass` says which of the lane's rays take it
+    auto exact_stage_xyz = [&](int tri, v3 X, v3 Y, v3 Z, const bool (&pass)[K]) {
 #pragma unroll
         for (int k = 0; k < K; k++) {
             if (!EXACT) n_cand += __popcll(__ballot(pass[k]));
@@ -607,6 +608,10 @@ __launch_bounds__(BLOCK) void traverse_kernel(TraverseParams p)
                 exact_pair<ANYHIT>(o, d, X, Y, Z, tri, tbest[k], idbest[k], occ[k]);
             }
         }
+    };
+    // ... with the vertices read from the mesh (the rare second level of the filtered forms)
+    auto exact_stage = [&](int tri, const bool (&pass)[K]) {
+        exact_stage_xyz(tri, vpos(p.verts, 3 * tri), vpos(p.verts, 3 * tri + 1), vpos(p.verts, 3 * tri + 2), pass);
     };
 
     // FORM 1: queue of (triangle, ray) pairs that passed the cone test, one per wavefront
@@ -694,7 +699,7 @@ __launch_bounds__(BLOCK) void traverse_kernel(TraverseParams p)
             __syncthreads();
         }
         const int tile_n = min(TSZ, t_end - tile_base); // triangles of this tile that belong to the range
-        if (FORM == 1) {
+        if (FORM == 1 && !EXACT) {
             const float4 *cs = reinterpret_cast<const float4 *>(p.cones);
 #pragma unroll
             for (int i = 0; i < CONE_TILE / BLOCK; i++) {
@@ -713,6 +718,17 @@ __launch_bounds__(BLOCK) void traverse_kernel(TraverseParams p)
             }
         } else if (!EXACT) {
             load_tile_moment(lds4, p.mrecs, tile_base, p.num_tris, tid);
+        } else {
+            // all-pairs mode: the tile holds the triangles' vertex positions themselves, three float4 per
+            // triangle, copied cooperatively from the reference's 32-byte records and read back with
+            // wave-uniform addresses (LDS broadcast) -- the loop of trace.glsl:135-157 as written
+            const float4 *src = reinterpret_cast<const float4 *>(p.verts);
+#pragma unroll
+            for (int i = 0; i < (TILE * 3) / BLOCK; i++) {
+                const int e = i * BLOCK + tid; // vertex of the tile
+                const int vtx = 3 * tile_base + e;
+                lds4[e] = (vtx < 3 * p.num_tris) ? src[2 * (size_t)vtx] : make_float4(qn, qn, qn, qn);
+            }
         }
         __syncthreads();
         tris_done += tile_n;
@@ -723,11 +739,14 @@ __launch_bounds__(BLOCK) void traverse_kernel(TraverseParams p)
         if (ANYHIT && wave_decided) continue;
 
         if (EXACT) {
-            for (int j = 0; j < tile_n; j++) {
-                bool pass[K];
+            bool pass[K];
 #pragma unroll
-                for (int k = 0; k < K; k++) pass[k] = valid[k];
-                if (tile_base + j < p.num_tris) exact_stage(tile_base + j, pass);
+            for (int k = 0; k < K; k++) pass[k] = valid[k];
+            const int tile_tris = min(tile_n, p.num_tris - tile_base);
+            for (int j = 0; j < tile_tris; j++) {
+                const float4 X = lds4[3 * j], Y = lds4[3 * j + 1], Z = lds4[3 * j + 2];
+                exact_stage_xyz(tile_base + j, rtx::V(X.x, X.y, X.z), rtx::V(Y.x, Y.y, Y.z),
+                                rtx::V(Z.x, Z.y, Z.z), pass);
             }
         } else if (FORM == 0) {
             const float *tile = reinterpret_cast<const float *>(lds4);
@@ -1245,38 +1264,34 @@ __global__ __launch_bounds__(BLOCK) void traverse_grid_kernel(TraverseParams p)
 
 // ---------------------------------------------------------------------------
 // Clustered closest-hit traversal of arbitrary rays (bounce passes).  Same result as
-// traverse_kernel<K, 0, false, *>, bit for bit, from two sweeps over GROUPS of triangles that
-// together cover every pair the reference's arithmetic could accept (rt_filter.h, "Plane-band
-// test and cluster spheres"):
-//   sweep A  triangles grouped by normal direction, 64 per group: is the ray's direction in the
-//            group's band?  For each ray that is, one lane per member tests the member's own
-//            band; pairs inside go to a queue and from there, one per lane, through the general
-//            edge filter and the reference arithmetic.
-//   sweep B  triangles grouped in space, 32 per cluster: does the ray's line pass the cluster's
-//            sphere?  For each ray that does (two per step), one lane per member runs the
-//            general edge filter on the member's record, then the reference arithmetic.
-// A wavefront tests its 64 K rays against a group with one ballot per K, loads the group's member
-// records once and then walks the set bits.  Results merge through the 64-bit atomicMin on
-// (t bits, index), so the visiting order does not matter.  The workgroup's rays are staged in
-// LDS so that any lane can fetch any of them.
-// grid = (ray blocks, sub-ranges): blockIdx.y takes a share of the groups of either kind.
+// traverse_kernel<K, 0, false, *>, bit for bit, from two sweeps that together cover every pair the
+// reference's arithmetic could accept (rt_filter.h, "Plane-band test"):
+//   band sweep   the ill-conditioned pairs: direction nearly in the triangle's plane and origin nearly
+//                on it.  Three kernels, by what the launch has: lists per direction cell
+//                (traverse_bandcell_kernel), rays sorted by direction (traverse_band_kernel), or
+//                neither (traverse_group_kernel, below).
+//   space sweep  the well-conditioned pairs: a walk over cells in space (traverse_voxel_kernel).
+// Results merge through the 64-bit atomicMin on (t bits, index), so the order of the visits does not
+// matter.
+//
+// traverse_group_kernel: triangles grouped by normal direction, 64 per group: is the ray's direction
+// in the group's band?  For each ray that is, one lane per member tests the member's own band and
+// slab; pairs inside go to a queue and from there, one per lane, through the general edge filter and
+// the reference arithmetic.  A wavefront tests its 64 rays against a group with one ballot, loads the
+// group's member records once and then walks the set bits.  The workgroup's rays are staged in LDS so
+// that any lane can fetch any of them.
+// grid = (ray blocks, sub-ranges of the groups).
 // ---------------------------------------------------------------------------
-constexpr int CLUSTER = 32;
 constexpr int NGROUP = 64;
 constexpr int SUBGROUP = 8;
 constexpr int GROUP_TILE = 256; // group records per LDS tile (4 KiB)
 
-template <int K, int SWEEPS>
-// The sphere sweep on its own (K = 1, SWEEPS = 2) lives on occupancy -- its member loop waits on record
-// reads -- and fits eight wavefronts per SIMD (64 VGPRs, 17 KiB of LDS per workgroup): 6 % faster than
-// the seven the register allocator settles for.
-__global__ __attribute__((amdgpu_waves_per_eu((K == 1 && SWEEPS == 2) ? 8 : 1, 8)))
-__launch_bounds__(BLOCK) void traverse_cluster_kernel(TraverseParams p)
+__global__ __launch_bounds__(BLOCK) void traverse_group_kernel(TraverseParams p)
 {
-    constexpr int NR = BLOCK * K;
+    constexpr int NR = BLOCK;
     __shared__ float4 tile[GROUP_TILE];
-    // the workgroup's rays: (unit direction, |g|) for sweep A, (origin, slot), (direction * |g|, -)
-    __shared__ float4 ray_b[(SWEEPS & 1) ? NR : 1], ray_o[NR], ray_h[NR];
+    // the workgroup's rays: (unit direction, |g|), (origin, slot), (direction * |g|, -)
+    __shared__ float4 ray_b[NR], ray_o[NR], ray_h[NR];
     __shared__ unsigned int queue_all[(BLOCK / 64) * qcap(1)];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1285,67 +1300,39 @@ __launch_bounds__(BLOCK) void traverse_cluster_kernel(TraverseParams p)
     if (s0 >= n) return;
     const int g_per_y = (p.num_ngroups + (int)gridDim.y - 1) / (int)gridDim.y;
     const int g_begin = blockIdx.y * g_per_y, g_end = min(g_begin + g_per_y, p.num_ngroups);
-    const int c_per_y = (p.num_clusters + (int)gridDim.y - 1) / (int)gridDim.y;
-    const int c_begin = blockIdx.y * c_per_y, c_end = min(c_begin + c_per_y, p.num_clusters);
 
-    float ox[K], oy[K], oz[K], bx[K], by[K], bz[K];
-    bool valid[K], wild[K];
     const float qn = __int_as_float(0x7fc00000);
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-        const int r = (wave * K + k) * 64 + lane;
-        const int s = s0 + r;
-        valid[k] = s < n;
-        const int sl = valid[k] ? (p.alist ? p.alist[s] : s) : 0;
-        ox[k] = oy[k] = oz[k] = bx[k] = by[k] = bz[k] = qn;
-        float dx = qn, dy = qn, dz = qn, g = qn;
-        if (valid[k]) {
-            ox[k] = p.job.ox[sl]; oy[k] = p.job.oy[sl]; oz[k] = p.job.oz[sl];
+    const int r_own = wave * 64 + lane;
+    const bool valid = s0 + r_own < n;
+    float bx = qn, by = qn, bz = qn;
+    bool wild;
+    {
+        const int sl = valid ? (p.alist ? p.alist[s0 + r_own] : s0 + r_own) : 0;
+        float ox = qn, oy = qn, oz = qn, dx = qn, dy = qn, dz = qn, g = qn;
+        if (valid) {
+            ox = p.job.ox[sl]; oy = p.job.oy[sl]; oz = p.job.oz[sl];
             dx = p.job.dx[sl]; dy = p.job.dy[sl]; dz = p.job.dz[sl];
-            bx[k] = p.job.bx[sl]; by[k] = p.job.by[sl]; bz[k] = p.job.bz[sl];
+            bx = p.job.bx[sl]; by = p.job.by[sl]; bz = p.job.bz[sl];
             g = p.job.g[sl];
         }
         // outside the range the band records were built for: every band holds this ray
-        wild[k] = valid[k] && !(g > 0.0f);
+        wild = valid && !(g > 0.0f);
         const float gg = fabsf(g);
-        if (SWEEPS & 1) ray_b[r] = make_float4(bx[k], by[k], bz[k], gg);
-        ray_o[r] = make_float4(ox[k], oy[k], oz[k], __int_as_float(sl));
-        ray_h[r] = make_float4(dx * gg, dy * gg, dz * gg, 0.0f);
+        ray_b[r_own] = make_float4(bx, by, bz, gg);
+        ray_o[r_own] = make_float4(ox, oy, oz, __int_as_float(sl));
+        ray_h[r_own] = make_float4(dx * gg, dy * gg, dz * gg, 0.0f);
     }
-    unsigned long long wild_mask[K], valid_mask[K];
-    bool any_wild = false;
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-        wild_mask[k] = __builtin_amdgcn_ballot_w64(wild[k]);
-        valid_mask[k] = __builtin_amdgcn_ballot_w64(valid[k]);
-        any_wild = any_wild || wild_mask[k] != 0ull;
-    }
+    const unsigned long long wild_mask = __builtin_amdgcn_ballot_w64(wild);
+    const unsigned long long valid_mask = __builtin_amdgcn_ballot_w64(valid);
 
     unsigned int *queue = queue_all + wave * qcap(1);
     int qcount = 0; // wave-uniform
     unsigned long long n_cand = 0, n_slow = 0;
 
-    // the reference arithmetic on one pair whose edge filter passed (rare: the direction comes
+    // the queue: (triangle, ray) pairs inside a plane band and slab, one per lane -- the general edge
+    // filter, then the reference arithmetic on the pairs it lets through (rare: the direction comes
     // from global memory)
-    auto confirm = [&](int r, int tri) {
-        const float4 ro = ray_o[r];
-        const int sl = __float_as_int(ro.w);
-        const v3 o = rtx::V(ro.x, ro.y, ro.z), d = rtx::V(p.job.dx[sl], p.job.dy[sl], p.job.dz[sl]);
-        const v3 X = vpos(p.verts, 3 * tri), Y = vpos(p.verts, 3 * tri + 1), Z = vpos(p.verts, 3 * tri + 2);
-        float t;
-        if (rtx::ray_vs_triangle(o, d, X, Y, Z, t) && t > 0.0f) {
-            const unsigned long long key =
-                ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)(unsigned int)tri;
-            atomicMin(&p.best[sl], key);
-        }
-    };
-
-    // sweep A's queue: (triangle, ray) pairs inside a plane band and slab, one per lane
     auto drain_pairs = [&](bool all) {
-#ifdef RT_DBG_NO_DRAIN
-        qcount = 0;
-        return;
-#endif
         while (qcount >= 64 || (all && qcount > 0)) {
             const int take = qcount >= 64 ? 64 : qcount;
             qcount -= take;
@@ -1360,7 +1347,18 @@ __launch_bounds__(BLOCK) void traverse_cluster_kernel(TraverseParams p)
                                            rh.z) >= -1.0f;
             }
             n_cand += __popcll(__builtin_amdgcn_ballot_w64(pass));
-            if (pass) confirm(r, tri);
+            if (pass) {
+                const float4 ro = ray_o[r];
+                const int sl = __float_as_int(ro.w);
+                const v3 o = rtx::V(ro.x, ro.y, ro.z), d = rtx::V(p.job.dx[sl], p.job.dy[sl], p.job.dz[sl]);
+                const v3 X = vpos(p.verts, 3 * tri), Y = vpos(p.verts, 3 * tri + 1), Z = vpos(p.verts, 3 * tri + 2);
+                float t;
+                if (rtx::ray_vs_triangle(o, d, X, Y, Z, t) && t > 0.0f) {
+                    const unsigned long long key =
+                        ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)(unsigned int)tri;
+                    atomicMin(&p.best[sl], key);
+                }
+            }
         }
     };
     auto push_pairs = [&](bool in, int tri, int r) {
@@ -1372,34 +1370,8 @@ __launch_bounds__(BLOCK) void traverse_cluster_kernel(TraverseParams p)
         }
     };
 
-    // sweep B's queue: pairs that passed the edge filter, for the reference arithmetic with one pair per lane
-    auto drain_hits = [&](bool all) {
-        while (qcount >= 64 || (all && qcount > 0)) {
-            const int take = qcount >= 64 ? 64 : qcount;
-            qcount -= take;
-            if (lane < take) {
-                const unsigned int e = queue[qcount + lane];
-                confirm((int)(e & 2047u), (int)(e >> 11));
-            }
-        }
-    };
-    auto push_hits = [&](bool in, int tri, int r) {
-        const unsigned long long h = __builtin_amdgcn_ballot_w64(in);
-        if (h) {
-            n_cand += __popcll(h);
-            if (in) queue[qcount + lanes_below(h)] = ((unsigned int)tri << 11) | (unsigned int)r;
-            qcount += __popcll(h);
-            if (qcount >= qcap(1) - 64) drain_hits(false);
-        }
-    };
-
     __syncthreads(); // the staged rays
 
-    // ---- sweep A: groups by normal direction
-#ifdef RT_DBG_NO_A
-    if (false)
-#endif
-    if (SWEEPS & 1)
     for (int tile_base = g_begin; tile_base < g_end; tile_base += GROUP_TILE) {
         __syncthreads();
         const int tile_n = min(GROUP_TILE, g_end - tile_base);
@@ -1411,139 +1383,53 @@ __launch_bounds__(BLOCK) void traverse_cluster_kernel(TraverseParams p)
         __syncthreads();
         for (int j = 0; j < tile_n; j++) {
             const float4 c = tile[j];
-            unsigned long long m[K], any = 0;
-#pragma unroll
-            for (int k = 0; k < K; k++) {
-                const float t = fabsf(fmaf(c.z, bz[k], fmaf(c.y, by[k], c.x * bx[k])));
-                m[k] = (__builtin_amdgcn_ballot_w64(t < c.w) | wild_mask[k]) & valid_mask[k];
-                any |= m[k];
-            }
-            if (!any) continue;
+            const float tg = fabsf(fmaf(c.z, bz, fmaf(c.y, by, c.x * bx)));
+            const unsigned long long m = (__builtin_amdgcn_ballot_w64(tg < c.w) | wild_mask) & valid_mask;
+            if (!m) continue;
             n_slow++;
             // one lane per member: (n/theta, kappa/H), (n/H, triangle)
             const float4 *mr = p.nrecs + (size_t)((tile_base + j) * NGROUP + lane) * 2;
             const float4 m1 = mr[0], m2 = mr[1];
             const int tri = __float_as_int(m2.w);
-#pragma unroll
-            for (int k = 0; k < K; k++) {
-                unsigned long long mk = m[k] & ~wild_mask[k];
-                const int rbase = (wave * K + k) * 64;
-                if (mk) {
-                    // the next ray's record is fetched while the current one is tested
-                    int src = __builtin_ctzll(mk);
-                    mk &= mk - 1;
-                    float4 rb = ray_b[rbase + src], ro = ray_o[rbase + src];
-                    for (;;) {
-                        const bool more = mk != 0ull;
-                        int nsrc = 0;
-                        float4 nb = rb, no = ro;
-                        if (more) {
-                            nsrc = __builtin_ctzll(mk);
-                            mk &= mk - 1;
-                            nb = ray_b[rbase + nsrc];
-                            no = ray_o[rbase + nsrc];
-                        }
-                        const float t = fmaf(m1.z, rb.z, fmaf(m1.y, rb.y, m1.x * rb.x));
-                        const float h = fmaf(m2.z, ro.z, fmaf(m2.y, ro.y, fmaf(m2.x, ro.x, -m1.w)));
-                        push_pairs(fmaxf(fabsf(t), fabsf(h)) < 1.0f, tri, rbase + src);
-                        if (!more) break;
-                        src = nsrc; rb = nb; ro = no;
+            unsigned long long mk = m & ~wild_mask;
+            const int rbase = wave * 64;
+            if (mk) {
+                // the next ray's record is fetched while the current one is tested
+                int src = __builtin_ctzll(mk);
+                mk &= mk - 1;
+                float4 rb = ray_b[rbase + src], ro = ray_o[rbase + src];
+                for (;;) {
+                    const bool more = mk != 0ull;
+                    int nsrc = 0;
+                    float4 nb = rb, no = ro;
+                    if (more) {
+                        nsrc = __builtin_ctzll(mk);
+                        mk &= mk - 1;
+                        nb = ray_b[rbase + nsrc];
+                        no = ray_o[rbase + nsrc];
                     }
+                    const float t = fmaf(m1.z, rb.z, fmaf(m1.y, rb.y, m1.x * rb.x));
+                    const float h = fmaf(m2.z, ro.z, fmaf(m2.y, ro.y, fmaf(m2.x, ro.x, -m1.w)));
+                    push_pairs(fmaxf(fabsf(t), fabsf(h)) < 1.0f, tri, rbase + src);
+                    if (!more) break;
+                    src = nsrc; rb = nb; ro = no;
                 }
-                // rays outside the records' range: every member that can be accepted at all
-                unsigned long long wk = m[k] & wild_mask[k];
-                while (wk) {
-                    const int src = __builtin_ctzll(wk);
-                    wk &= wk - 1;
-                    push_pairs(tri >= 0 && m1.w != 2.0f, tri, rbase + src);
-                }
+            }
+            // rays outside the records' range: every member that can be accepted at all
+            unsigned long long wk = m & wild_mask;
+            while (wk) {
+                const int src = __builtin_ctzll(wk);
+                wk &= wk - 1;
+                push_pairs(tri >= 0 && m1.w != 2.0f, tri, rbase + src);
             }
         }
     }
     drain_pairs(true);
 
-    // ---- sweep B: clusters in space (a ray outside the records' range is in every band, so sweep A
-    //      has queued all its pairs)
-#ifdef RT_DBG_NO_B
-    if (false)
-#endif
-    if (SWEEPS & 2)
-    for (int tile_base = c_begin; tile_base < c_end; tile_base += GROUP_TILE) {
-        __syncthreads();
-        const int tile_n = min(GROUP_TILE, c_end - tile_base);
-#pragma unroll
-        for (int i = 0; i < GROUP_TILE / BLOCK; i++) {
-            const int e = i * BLOCK + tid;
-            if (e < tile_n) tile[e] = p.spheres[tile_base + e];
-        }
-        __syncthreads();
-        for (int j = 0; j < tile_n; j++) {
-            const float4 c = tile[j];
-            unsigned long long m[K], any = 0;
-#pragma unroll
-            for (int k = 0; k < K; k++) {
-                const bool in = rtf::cluster_test(&c.x, ox[k], oy[k], oz[k], bx[k], by[k], bz[k]);
-                m[k] = __builtin_amdgcn_ballot_w64(in) & ~wild_mask[k];
-                any |= m[k];
-            }
-            if (!any) continue;
-            n_slow++;
-            // one lane per member (twice): its general edge record
-            const int idx = (tile_base + j) * CLUSTER + (lane & 31);
-            const float4 *rp = reinterpret_cast<const float4 *>(p.crecs + idx);
-            const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
-            const float rec[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
-            const int tri = p.members[idx];
-#pragma unroll
-            for (int k = 0; k < K; k++) {
-                unsigned long long mk = m[k];
-                const int rbase = (wave * K + k) * 64;
-                if (!mk) continue;
-                // the lower half of the wavefront takes the lowest set bit, the upper half the next;
-                // the records of the following pair of rays are fetched while this pair is tested
-                auto take2 = [&](int &src) {
-                    const int s0b = __builtin_ctzll(mk);
-                    mk &= mk - 1;
-                    int s1b = -1;
-                    if (mk) {
-                        s1b = __builtin_ctzll(mk);
-                        mk &= mk - 1;
-                    }
-                    src = (lane < 32) ? s0b : s1b;
-                };
-                int src;
-                take2(src);
-                float4 ro = ray_o[rbase + (src < 0 ? 0 : src)], rh = ray_h[rbase + (src < 0 ? 0 : src)];
-                for (;;) {
-                    const bool more = mk != 0ull;
-                    int nsrc = -1;
-                    float4 no = ro, nh = rh;
-                    if (more) {
-                        take2(nsrc);
-                        no = ray_o[rbase + (nsrc < 0 ? 0 : nsrc)];
-                        nh = ray_h[rbase + (nsrc < 0 ? 0 : nsrc)];
-                    }
-                    bool pass = false;
-                    if (src >= 0 && tri >= 0)
-                        pass = rtf::filter_general(rec, ro.x, ro.y, ro.z, rh.x, rh.y, rh.z) >= -1.0f;
-                    push_hits(pass, tri, rbase + (src < 0 ? 0 : src));
-                    if (!more) break;
-                    src = nsrc; ro = no; rh = nh;
-                }
-            }
-        }
-    }
-    drain_hits(true);
-
     if (lane == 0) {
         add_counter(p.counters, C_CH_CAND, n_cand);
         add_counter(p.counters, C_CH_SLOW, n_slow);
     }
-    if (tid == 0 && blockIdx.y == 0 && (SWEEPS & 2)) {
-        const int mine = min(NR, n - s0);
-        add_counter(p.counters, C_CH_PAIRS, (unsigned long long)mine * (unsigned long long)p.num_tris);
-    }
-    (void)any_wild;
 }
 
 // ---------------------------------------------------------------------------
@@ -1554,7 +1440,7 @@ __launch_bounds__(BLOCK) void traverse_cluster_kernel(TraverseParams p)
 // inside a member's band and slab is queued; the queue is handled 64 pairs at a time, one per lane:
 // general edge filter, then the reference arithmetic (doing either on the spot stalls the whole
 // wavefront on a chain of dependent loads for the sake of a lane or two).
-// Same pairs reach the reference arithmetic as in sweep A of traverse_cluster_kernel.
+// Same pairs reach the reference arithmetic as in traverse_group_kernel.
 // grid = (ray blocks, sub-ranges of the groups).
 // ---------------------------------------------------------------------------
 constexpr int BAND_TILE_GROUPS = 8; // groups per LDS tile: 512 member records of 32 bytes (16 KiB)
@@ -1893,6 +1779,116 @@ __global__ __launch_bounds__(BLOCK) void traverse_bandcell_kernel(TraverseParams
     if (!valid) return;
     const unsigned long long key = best[lane];
     if (key != BEST_NONE) atomicMin(&p.best[sl], key);
+}
+
+// ---------------------------------------------------------------------------
+// Closest-hit traversal of arbitrary rays over cells in space (rt_voxel.h): the well-conditioned
+// pairs of a bounce pass -- the ill-conditioned ones are the band sweep's.  One ray per lane,
+// wavefronts independent, no LDS.  A lane walks the cells along its ray's line front to back; per
+// step of the loop it either moves to the next cell or puts one triangle of the current cell's list
+// through the general edge filter.  A triangle that passes becomes the lane's candidate; candidates
+// go through the reference arithmetic together -- when VOXEL_FLUSH_MIN lanes hold one, or a lane needs
+// its slot for the next -- each lane on its own ray, keeping the smallest (t, index).  The walk of a
+// lane ends when it leaves the grid or no cell further on can hold a hit with a computed t at or
+// below the lane's best (rtv::walk_done).  Results merge into p.best by the 64-bit atomicMin.
+// A walk starts from the best hit recorded so far in p.best (whoever found it: any accepted hit bounds
+// the answer).
+// Rays outside the band records' range (job.g <= 0) and rays no filter passes (job.g NaN) do not walk.
+// grid = ray blocks of 256.
+// ---------------------------------------------------------------------------
+constexpr int VOXEL_FLUSH_MIN = 16;
+
+__global__ __launch_bounds__(BLOCK) void traverse_voxel_kernel(TraverseParams p)
+{
+    const int tid = threadIdx.x;
+    const int n = p.count ? *p.count : p.n;
+    const int s = blockIdx.x * BLOCK + tid;
+    if ((s & ~63) >= n) return; // the whole wavefront
+    const bool valid = s < n;
+    const int sl = valid ? (p.alist ? p.alist[s] : s) : 0;
+    const float qn = __int_as_float(0x7fc00000);
+    float ox = qn, oy = qn, oz = qn, dx = qn, dy = qn, dz = qn, g = qn;
+    float tbest = INFINITY;
+    int idbest = 0;
+    if (valid) {
+        ox = p.job.ox[sl]; oy = p.job.oy[sl]; oz = p.job.oz[sl];
+        dx = p.job.dx[sl]; dy = p.job.dy[sl]; dz = p.job.dz[sl];
+        g = p.job.g[sl];
+        const unsigned long long key = p.best[sl];
+        tbest = __uint_as_float((unsigned int)(key >> 32));
+        idbest = (int)(unsigned int)(key & 0xffffffffull);
+    }
+    const float tfirst = tbest;
+    const int idfirst = idbest;
+    bool active = valid && g > 0.0f;
+    const float hx = dx * g, hy = dy * g, hz = dz * g;
+    const rtv::Grid &G = p.vox;
+    rtv::Walk w{};
+    if (active) active = rtv::walk_start(G, ox, oy, oz, dx, dy, dz, w);
+    unsigned int idx = 0, end = 0;
+    if (active) {
+        const int cell = rtv::cell_index(G, w);
+        idx = p.vox_off[cell];
+        end = p.vox_off[cell + 1];
+    }
+    int cand = -1;
+    unsigned long long n_cand = 0, n_slow = 0;
+
+    // the reference arithmetic on every lane's candidate
+    auto flush = [&]() {
+        n_cand += __popcll(__builtin_amdgcn_ballot_w64(cand >= 0));
+        if (cand >= 0) {
+            const v3 X = vpos(p.verts, 3 * cand), Y = vpos(p.verts, 3 * cand + 1), Z = vpos(p.verts, 3 * cand + 2);
+            float t;
+            if (rtx::ray_vs_triangle(rtx::V(ox, oy, oz), rtx::V(dx, dy, dz), X, Y, Z, t) && t > 0.0f &&
+                (t < tbest || (t == tbest && cand < idbest))) {
+                tbest = t;
+                idbest = cand;
+            }
+        }
+        cand = -1;
+    };
+
+    while (any64(active)) {
+        n_slow++;
+        if (__popcll(__builtin_amdgcn_ballot_w64(cand >= 0)) >= VOXEL_FLUSH_MIN) flush();
+        if (active && idx >= end) {
+            // the next cell, unless nothing from there on can matter
+            if (!rtv::walk_step(G, ox, oy, oz, w) || rtv::walk_done(G, w, tbest)) {
+                active = false;
+            } else {
+                const int cell = rtv::cell_index(G, w);
+                idx = p.vox_off[cell];
+                end = p.vox_off[cell + 1];
+            }
+        }
+        bool pass = false;
+        int tri = 0;
+        if (active && idx < end) {
+            tri = p.vox_entries[idx++];
+            // (the triangle that holds the best hit, or is about to be tested, shows up again in the cells next to it)
+            if ((tri != idbest || !(tbest < INFINITY)) && tri != cand) {
+                const float4 *rp = reinterpret_cast<const float4 *>(p.recs + tri);
+                const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
+                const float rec[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
+                pass = rtf::filter_general(rec, ox, oy, oz, hx, hy, hz) >= -1.0f;
+            }
+        }
+        if (any64(pass && cand >= 0)) flush(); // a lane needs its slot
+        if (pass) cand = tri;
+    }
+    flush();
+
+    if ((tid & 63) == 0) {
+        add_counter(p.counters, C_CH_CAND, n_cand);
+        add_counter(p.counters, C_CH_SLOW, n_slow);
+        add_counter(p.counters, C_CH_PAIRS, (unsigned long long)min(64, n - (s & ~63)) * (unsigned long long)p.num_tris);
+    }
+    if (valid && (tbest < tfirst || (tbest == tfirst && idbest < idfirst))) {
+        const unsigned long long key =
+            ((unsigned long long)__float_as_uint(tbest) << 32) | (unsigned long long)(unsigned int)idbest;
+        atomicMin(&p.best[sl], key);
+    }
 }
 
 // ---------------------------------------------------------------------------

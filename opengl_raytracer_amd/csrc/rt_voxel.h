@@ -1,0 +1,314 @@
+// rt_voxel.h -- a uniform grid of cells in space for the closest-hit traversal of arbitrary rays
+// (bounce passes): per cell, the list of triangles that come within rho of it; a ray walks the cells
+// along its line front to back, tests the triangles listed there, and stops as soon as no cell
+// further on can hold a hit that beats the one it has.
+//
+// Which pairs this covers.  rt_filter.h ("Plane-band test") splits the pairs
+// the reference's arithmetic can accept in two: (B) ill-conditioned ones -- direction nearly in the
+// triangle's plane and origin nearly on it -- which the band sweep finds, and (A) well-conditioned
+// ones, |a^| >= K E, for which the point P where the ray's LINE meets the triangle's plane lies within
+// rho of the triangle.  The walk finds every pair of kind (A) that can matter:
+//   * the build lists triangle k in every cell that comes within rho_k + m of it (m: the margin that
+//     covers the walk's rounding, below), so the cell that holds P lists k;
+//   * P = o + t d with t >= -0.22 rho / |d| (a computed t^ > 0 forces that, see the bound on t^ below),
+//     so a walk that starts rho_max + m behind the origin and visits every cell the line crosses from
+//     there on meets the cell of P;
+//   * for a pair of kind (A) the computed t^ and the exact t are tied by
+//         t^ >= 0.948 t - 0.0523 min(|e1|,|e2|) / |d|        (t >= 0)
+//     [t^ = N^t / a^ (1 + 2 eps); |N^t - Nt| <= 8 eps |s||e1||e2| and |a^| >= K 9 eps |d| S max|e|
+//     give |dNt / a^| <= 8/(9K) min|e| / |d| = 0.0523 min|e| / |d|; |a^ - a| <= 7/8 E <= 7/(8K) |a^|
+//     gives t (1 - 0.0515)], and rho = 0.1275 (|e1| + |e2|) >= 0.255 min|e|, so
+//         t^ >= 0.94 t - 0.25 rho_max / |d|   with room to spare.
+//     A cell entered at parameter T therefore holds only hit points with t >= T, whose computed
+//     t^ is at least 0.94 T - 0.25 rho_max/|d|: once that exceeds the best t^ found so far, nothing
+//     further on can replace it (equal t^ does not stop the walk, so the lowest index among equal
+//     t^ is still found), and the walk ends.
+// Triangles that take no part (never accepted, or "always in the band": too large, slivers) are not
+// listed; the band sweep tests those against every ray.  Rays outside the band records' range
+// ("wild") do not walk: the band sweep has all their pairs.
+//
+// Rounding of the walk.  The walk keeps, per axis, the parameter at which the line leaves the
+// current cell, computed from the cell's index each time: t_k = (gmin + i cs - o) / d, off from the
+// exact crossing by a few ulp of its operands -- in position along that axis less than
+// 3e-7 abs_extent, whatever the size of d.  At any parameter the walk's cell therefore differs
+// from the exact one only along axes whose crossing lies within that error: the point is within
+// m = 2^-18 abs_extent + 2^-12 cs of the walk's cell, which is what the build allows for.  An axis
+// along which the ray moves less than m/4 over the whole box is not stepped at all.
+//
+// The walk compiles for the device (hipcc) and for the host (tests/native/filter_model.cpp); the build
+// at the end is host code.
+#pragma once
+
+#include "rt_filter.h"
+
+#include "../../include/rt.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+namespace rtv {
+
+struct Grid {         // (named members, not arrays: an axis chosen per lane must not become an indexed load)
+    float gminx, gminy, gminz; // lower corner of cell (0, 0, 0)
+    float gmaxx, gmaxy, gmaxz; // upper corner of the last cell
+    float cs;        // edge length of the (cubic) cells
+    float inv_cs;
+    int nx, ny, nz;  // cells per axis
+    float back;      // distance: the walk starts this far behind the ray's origin (rho_max + margin)
+    float slack;     // distance: 0.25 rho_max, the absolute term of the bound on t^
+    float flat;      // an axis with |d_axis| <= |d| * flat is not stepped
+};
+
+constexpr float STOP_FACTOR = 0.94f;
+
+RT_HD float plane_at(const Grid &G, float gmin, int i) { return fmaf((float)i, G.cs, gmin); }
+
+struct Walk {
+    int ix, iy, iz;          // the current cell
+    float tx, ty, tz;        // parameter at which the line leaves it along each axis (+inf: never)
+    float invx, invy, invz;  // 1 / d per axis; its sign is the step's direction
+    float t_enter;           // parameter at which the current cell was entered
+    float inv_dn;            // 1 / |d|
+};
+
+RT_HD int cell_index(const Grid &G, const Walk &w) { return (w.iz * G.ny + w.iy) * G.nx + w.ix; }
+
+// one axis of the slab clip; false: the line misses the box
+RT_HD bool clip_axis(float o, float d, float inv, bool flat, float lo, float hi, float &t0, float &t1)
+{
+    if (flat) return o >= lo && o <= hi;
+    const float ta = (lo - o) * inv, tb = (hi - o) * inv;
+    t0 = fmaxf(t0, fminf(ta, tb));
+    t1 = fminf(t1, fmaxf(ta, tb));
+    return true;
+}
+
+RT_HD float exit_param(const Grid &G, float gmin, int i, float o, float inv, bool flat)
+{
+    if (flat) return INFINITY;
+    return (plane_at(G, gmin, inv > 0.0f ? i + 1 : i) - o) * inv;
+}
+
+RT_HD int start_index(float p, float gmin, float inv_cs, int n)
+{
+    const float q = floorf((p - gmin) * inv_cs);
+    if (!(q > 0.0f)) return 0;
+    if (q >= (float)n) return n - 1;
+    return (int)q;
+}
+
+// Places the walk in the cell where the line enters the grid (or rho_max + margin behind the ray's
+// origin, whichever comes later).  false: the line misses the grid, or the ray is not one the walk
+// handles (zero or non-finite direction).
+RT_HD bool walk_start(const Grid &G, float ox, float oy, float oz, float dx, float dy, float dz, Walk &w)
+{
+    const float dn = sqrtf(dx * dx + dy * dy + dz * dz);
+    if (!(dn > 0.0f) || !(dn < INFINITY)) return false;
+    w.inv_dn = 1.0f / dn;
+    const float lim = dn * G.flat;
+    const bool fx = !(fabsf(dx) > lim), fy = !(fabsf(dy) > lim), fz = !(fabsf(dz) > lim);
+    w.invx = 1.0f / dx; w.invy = 1.0f / dy; w.invz = 1.0f / dz;
+    float t0 = -G.back * w.inv_dn, t1 = INFINITY;
+    if (!clip_axis(ox, dx, w.invx, fx, G.gminx, G.gmaxx, t0, t1)) return false;
+    if (!clip_axis(oy, dy, w.invy, fy, G.gminy, G.gmaxy, t0, t1)) return false;
+    if (!clip_axis(oz, dz, w.invz, fz, G.gminz, G.gmaxz, t0, t1)) return false;
+    if (!(t0 <= t1)) return false;
+    w.t_enter = t0;
+    w.ix = start_index(fmaf(t0, dx, ox), G.gminx, G.inv_cs, G.nx);
+    w.iy = start_index(fmaf(t0, dy, oy), G.gminy, G.inv_cs, G.ny);
+    w.iz = start_index(fmaf(t0, dz, oz), G.gminz, G.inv_cs, G.nz);
+    w.tx = exit_param(G, G.gminx, w.ix, ox, w.invx, fx);
+    w.ty = exit_param(G, G.gminy, w.iy, oy, w.invy, fy);
+    w.tz = exit_param(G, G.gminz, w.iz, oz, w.invz, fz);
+    return true;
+}
+
+// Moves to the next cell along the line.  false: the walk has left the grid.  (Written without
+// branches on the axis: the lanes of a wavefront step along different axes.)
+RT_HD bool walk_step(const Grid &G, float ox, float oy, float oz, Walk &w)
+{
+    // (values first: a conditional expression over members is a conditional lvalue, which turns the
+    // struct into an indexed array in memory)
+    const float tx = w.tx, ty = w.ty, tz = w.tz, invx = w.invx, invy = w.invy, invz = w.invz;
+    const int ix = w.ix, iy = w.iy, iz = w.iz;
+    const float gx = G.gminx, gy = G.gminy, gz = G.gminz;
+    const int nx = G.nx, ny = G.ny, nz = G.nz;
+    const bool sx = tx <= ty && tx <= tz;
+    const bool sy = !sx && ty <= tz;
+    const float inv = sx ? invx : (sy ? invy : invz);
+    const float o = sx ? ox : (sy ? oy : oz);
+    const float gm = sx ? gx : (sy ? gy : gz);
+    const int nn = sx ? nx : (sy ? ny : nz);
+    int i = sx ? ix : (sy ? iy : iz);
+    w.t_enter = sx ? tx : (sy ? ty : tz);
+    const bool up = inv > 0.0f;
+    i += up ? 1 : -1;
+    // as exit_param() forms it
+    const float tn = (fmaf((float)(up ? i + 1 : i), G.cs, gm) - o) * inv;
+    w.ix = sx ? i : ix; w.tx = sx ? tn : tx;
+    w.iy = sy ? i : iy; w.ty = sy ? tn : ty;
+    w.iz = (sx || sy) ? iz : i; w.tz = (sx || sy) ? tz : tn;
+    return i >= 0 && i < nn;
+}
+
+// true: no cell from the current one on can hold a hit whose computed t^ is <= tbest
+RT_HD bool walk_done(const Grid &G, const Walk &w, float tbest)
+{
+    return fmaf(STOP_FACTOR, w.t_enter, -(G.slack * w.inv_dn)) > tbest;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host-side build.
+// ---------------------------------------------------------------------------------------------
+struct VoxelSet {
+    Grid grid{};
+    std::vector<uint32_t> off;     // cells + 1
+    std::vector<int32_t> entries;  // triangle indices, cell after cell
+    double rho_max = 0.0;
+    double margin = 0.0;
+};
+
+// Does the triangle (a, b, c), given relative to the box's centre, come within the box of half
+// sizes h?  Separating axes: the three box normals, the triangle's normal, the nine cross products.
+inline bool tri_box_overlap(const double a[3], const double b[3], const double c[3], const double h[3])
+{
+    for (int k = 0; k < 3; k++) {
+        const double lo = std::min(a[k], std::min(b[k], c[k])), hi = std::max(a[k], std::max(b[k], c[k]));
+        if (lo > h[k] || hi < -h[k]) return false;
+    }
+    const double e[3][3] = {{b[0] - a[0], b[1] - a[1], b[2] - a[2]},
+                            {c[0] - b[0], c[1] - b[1], c[2] - b[2]},
+                            {a[0] - c[0], a[1] - c[1], a[2] - c[2]}};
+    const double *v[3] = {a, b, c};
+    for (int i = 0; i < 3; i++)       // edge i
+        for (int k = 0; k < 3; k++) { // box axis k: axis = unit_k x e_i
+            const int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+            const double ax1 = -e[i][k2], ax2 = e[i][k1]; // components along k1, k2
+            double lo = 0.0, hi = 0.0;
+            for (int q = 0; q < 3; q++) {
+                const double p = ax1 * v[q][k1] + ax2 * v[q][k2];
+                if (q == 0 || p < lo) lo = p;
+                if (q == 0 || p > hi) hi = p;
+            }
+            const double r = std::fabs(ax1) * h[k1] + std::fabs(ax2) * h[k2];
+            if (lo > r || hi < -r) return false;
+        }
+    const double n[3] = {e[0][1] * e[1][2] - e[0][2] * e[1][1], e[0][2] * e[1][0] - e[0][0] * e[1][2],
+                         e[0][0] * e[1][1] - e[0][1] * e[1][0]};
+    const double dist = n[0] * a[0] + n[1] * a[1] + n[2] * a[2];
+    const double r = std::fabs(n[0]) * h[0] + std::fabs(n[1]) * h[1] + std::fabs(n[2]) * h[2];
+    return std::fabs(dist) <= r;
+}
+
+// rho[t] >= 0 marks the triangles that take part (the ones the band records leave to the spatial
+// sweep); res = cells along the longest axis of their bounding box, 0 = chosen from their number.
+// abs_extent bounds the magnitude of every coordinate involved (origins within the records' range
+// included).
+inline void build(const rt_vertex *v, int num_tris, const std::vector<double> &rho, double abs_extent, int res,
+                  VoxelSet &out)
+{
+    out = VoxelSet{};
+    Grid &G = out.grid;
+    float gmin[3] = {0.0f, 0.0f, 0.0f}, gmax[3] = {0.0f, 0.0f, 0.0f};
+    int gn[3] = {1, 1, 1};
+    auto store = [&]() {
+        G.gminx = gmin[0]; G.gminy = gmin[1]; G.gminz = gmin[2];
+        G.gmaxx = gmax[0]; G.gmaxy = gmax[1]; G.gmaxz = gmax[2];
+        G.nx = gn[0]; G.ny = gn[1]; G.nz = gn[2];
+    };
+    double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    size_t count = 0;
+    for (int t = 0; t < num_tris; t++) {
+        if (!(rho[t] >= 0.0)) continue;
+        out.rho_max = std::max(out.rho_max, rho[t]);
+        for (int k = 0; k < 3; k++)
+            for (int a = 0; a < 3; a++) {
+                const double x = v[3 * t + k].pos[a];
+                if (count == 0 || x < lo[a]) lo[a] = x;
+                if (count == 0 || x > hi[a]) hi[a] = x;
+            }
+        count++;
+    }
+    if (count == 0) { // an empty grid: one cell, no entries
+        G.cs = 1.0f; G.inv_cs = 1.0f; G.back = 0.0f; G.slack = 0.0f; G.flat = 0.0f;
+        gmin[0] = 1.0f; // gmin > gmax: every line misses
+        store();
+        out.off.assign(2, 0u);
+        return;
+    }
+    double longest = 0.0;
+    for (int a = 0; a < 3; a++) longest = std::max(longest, hi[a] - lo[a]);
+    if (res <= 0) res = (int)std::lround(std::cbrt(4.0 * (double)count));
+    res = std::max(1, std::min(res, 128));
+    double margin0 = abs_extent * 3.814697265625e-06; // 2^-18
+    double cs = std::max(longest / res, 64.0 * margin0);
+    if (!(cs > 0.0)) cs = 1.0;
+    G.cs = (float)cs;
+    cs = (double)G.cs;
+    G.inv_cs = (float)(1.0 / cs);
+    out.margin = margin0 + cs * 0.000244140625; // 2^-12
+    const double pad = out.rho_max + 4.0 * out.margin;
+    size_t ncell = 1;
+    for (int a = 0; a < 3; a++) {
+        gmin[a] = (float)(lo[a] - pad);
+        if ((double)gmin[a] > lo[a] - pad) gmin[a] = std::nextafterf(gmin[a], -INFINITY);
+        const double ext = hi[a] + pad - (double)gmin[a];
+        int n = (int)std::ceil(ext / cs) + 1;
+        n = std::max(1, std::min(n, 2 * 128 + 8));
+        gn[a] = n;
+        gmax[a] = plane_at(G, gmin[a], n);
+        ncell *= (size_t)n;
+    }
+    store();
+    double diag = 0.0;
+    for (int a = 0; a < 3; a++) diag += ((double)gmax[a] - gmin[a]) * ((double)gmax[a] - gmin[a]);
+    diag = std::sqrt(diag) + pad;
+    G.back = (float)(out.rho_max + out.margin);
+    G.slack = (float)(0.25 * out.rho_max * 1.001);
+    if ((double)G.slack < 0.25 * out.rho_max) G.slack = std::nextafterf(G.slack, INFINITY);
+    G.flat = (float)(0.25 * out.margin / diag);
+
+    // (cell, triangle) pairs, then a counting sort by cell
+    std::vector<uint32_t> cells;
+    std::vector<int32_t> tris;
+    std::vector<uint32_t> cnt(ncell + 1, 0u);
+    for (int t = 0; t < num_tris; t++) {
+        if (!(rho[t] >= 0.0)) continue;
+        const double g = rho[t] + out.margin;
+        int c0[3], c1[3];
+        for (int a = 0; a < 3; a++) {
+            double l = v[3 * t].pos[a], h = l;
+            for (int k = 1; k < 3; k++) {
+                l = std::min(l, (double)v[3 * t + k].pos[a]);
+                h = std::max(h, (double)v[3 * t + k].pos[a]);
+            }
+            c0[a] = std::max(0, std::min(gn[a] - 1, (int)std::floor((l - g - (double)gmin[a]) / cs)));
+            c1[a] = std::max(0, std::min(gn[a] - 1, (int)std::floor((h + g - (double)gmin[a]) / cs)));
+        }
+        const double hh[3] = {0.5 * cs + g, 0.5 * cs + g, 0.5 * cs + g};
+        for (int iz = c0[2]; iz <= c1[2]; iz++)
+            for (int iy = c0[1]; iy <= c1[1]; iy++)
+                for (int ix = c0[0]; ix <= c1[0]; ix++) {
+                    const double cc[3] = {(double)gmin[0] + (ix + 0.5) * cs, (double)gmin[1] + (iy + 0.5) * cs,
+                                          (double)gmin[2] + (iz + 0.5) * cs};
+                    double a[3], b[3], c[3];
+                    for (int q = 0; q < 3; q++) {
+                        a[q] = (double)v[3 * t].pos[q] - cc[q];
+                        b[q] = (double)v[3 * t + 1].pos[q] - cc[q];
+                        c[q] = (double)v[3 * t + 2].pos[q] - cc[q];
+                    }
+                    if (!tri_box_overlap(a, b, c, hh)) continue;
+                    const uint32_t cell = (uint32_t)(((size_t)iz * gn[1] + iy) * gn[0] + ix);
+                    cells.push_back(cell);
+                    tris.push_back(t);
+                    cnt[cell + 1]++;
+                }
+    }
+    for (size_t i = 0; i < ncell; i++) cnt[i + 1] += cnt[i];
+    out.off = cnt;
+    out.entries.assign(cells.size(), 0);
+    std::vector<uint32_t> cur(cnt.begin(), cnt.end() - 1);
+    for (size_t i = 0; i < cells.size(); i++) out.entries[cur[cells[i]]++] = tris[i];
+}
+} // namespace rtv

@@ -132,21 +132,28 @@ extern "C" void fm_check_cone(int n_tris, const float *verts, int n_rays, const 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Clustered traversal of arbitrary rays, as traverse_cluster_kernel evaluates it: a pair reaches
-// the reference arithmetic iff
+// Clustered traversal of arbitrary rays, as the bounce passes evaluate it: a pair reaches the
+// reference arithmetic iff
 //   (its triangle's normal group holds the ray's direction AND the triangle's own band and slab
 //    hold the ray, or the ray is outside the records' range)  AND the general edge filter passes,
-//   OR  (the ray is inside the range AND its line passes the sphere of the triangle's cluster)
-//        AND the general edge filter passes.
+//   OR  (the ray is inside the range AND its walk over the cells in space (rt_voxel.h) meets a cell
+//        that lists the triangle)  AND the general edge filter passes.
+// Checked twice: pair by pair with a walk that never stops early (every pair the oracle accepts must
+// reach the reference arithmetic), and ray by ray with the walk's stopping rule, the best hit updated
+// the moment a candidate is confirmed (the earliest any implementation can stop): the closest hit
+// (t bits, lowest index among equal t) must be the one the oracle's sequential loop keeps.
 // stats: [0] pairs [1] (ray, group) band passes x members [2] member band+slab passes
-//        [3] pairs inside a cluster sphere [4] pairs reaching the reference arithmetic
-//        [5] oracle accepts [6] violations [7] rays outside the records' range
-//        [8] triangles in no cluster [9] triangles that are never accepted
+//        [3] pairs the never-stopping walk visits [4] pairs reaching the reference arithmetic
+//        [5] oracle accepts [6] violations, pair by pair [7] rays outside the records' range
+//        [8] triangles that are in no cell [9] triangles that are never accepted
+//        [10] rays whose closest hit differs with the stopping rule [11] cells the stopping walks visit
+//        [12] triangles they put through the edge filter [13] rays that hit something
 // ---------------------------------------------------------------------------------------------
 #include "../../opengl_raytracer_amd/csrc/rt_cluster.h"
+#include "../../opengl_raytracer_amd/csrc/rt_voxel.h"
 
 extern "C" void fm_check_clustered(int n_tris, const float *verts, int n_rays, const float *org, const float *dir,
-                                   const float *center, float radius, long long *stats)
+                                   const float *center, float radius, int voxel_res, long long *stats)
 {
     std::vector<rt_vertex> v((size_t)n_tris * 3);
     for (int i = 0; i < n_tris * 3; i++) {
@@ -155,74 +162,134 @@ extern "C" void fm_check_clustered(int n_tris, const float *verts, int n_rays, c
     }
     rtc::ClusterSet cs;
     rtc::build(v.data(), n_tris, center, radius, cs);
-    std::vector<int> group_of(n_tris, -1), gpos(n_tris, -1), cluster_of(n_tris, -1), cpos(n_tris, -1);
+    rtv::VoxelSet vs;
+    const double abs_extent = std::sqrt((double)center[0] * center[0] + (double)center[1] * center[1] +
+                                        (double)center[2] * center[2]) + 3.0 * (double)radius;
+    rtv::build(v.data(), n_tris, cs.rho, abs_extent, voxel_res, vs);
+    const rtv::Grid &G = vs.grid;
+    std::vector<int> group_of(n_tris, -1), gpos(n_tris, -1);
     for (int g = 0; g < cs.num_ngroups; g++)
         for (int j = 0; j < rtc::NGROUP; j++) {
             const int t = cs.nmembers[(size_t)g * rtc::NGROUP + j];
             if (t >= 0) { group_of[t] = g; gpos[t] = g * rtc::NGROUP + j; }
         }
-    for (int c = 0; c < cs.num_clusters; c++)
-        for (int j = 0; j < rtc::CLUSTER; j++) {
-            const int t = cs.members[(size_t)c * rtc::CLUSTER + j];
-            if (t >= 0) { cluster_of[t] = c; cpos[t] = c * rtc::CLUSTER + j; }
-        }
+    std::vector<rtf::TriRec> grec(n_tris);
+    for (int k = 0; k < n_tris; k++) rtf::make_general_rec(verts + 9 * k, verts + 9 * k + 3, verts + 9 * k + 6, &grec[k]);
     long long pairs = 0, gp = 0, mp = 0, sp = 0, reach_exact = 0, acc = 0, bad = 0, wildn = 0, noclu = 0, never = 0;
+    long long bad_closest = 0, cells_n = 0, tests_n = 0, hits_n = 0;
     for (int k = 0; k < n_tris; k++) {
-        noclu += cluster_of[k] < 0;
+        noclu += !(cs.rho[k] >= 0.0);
         never += group_of[k] < 0;
     }
-#pragma omp parallel for reduction(+ : pairs, gp, mp, sp, reach_exact, acc, bad, wildn) schedule(static)
-    for (int i = 0; i < n_rays; i++) {
-        const float *o = org + 3 * i, *d = dir + 3 * i;
-        // prepare_general
-        const float ocx = o[0] - center[0], ocy = o[1] - center[1], ocz = o[2] - center[2];
-        const float dist = sqrtf(ocx * ocx + ocy * ocy + ocz * ocz);
-        const float g0 = rtf::dir_scale(dist + 3.0f * radius, d[0], d[1], d[2]);
-        const float inv = 1.0f / sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
-        const float bx = d[0] * inv, by = d[1] * inv, bz = d[2] * inv;
-        const float g = (dist <= 1.25f * radius) ? g0 : -g0;
-        const bool wild = !(g > 0.0f);
-        const float gg = fabsf(g);
-        wildn += wild;
-        for (int k = 0; k < n_tris; k++) {
-            const float *X = verts + 9 * k, *Y = X + 3, *Z = X + 6;
-            bool to_exact = false;
-            if (group_of[k] >= 0) {
-                const float *G = &cs.ngroups[(size_t)group_of[k] * 4];
-                const float tg = fabsf(fmaf(G[2], bz, fmaf(G[1], by, G[0] * bx)));
-                // the part of the group the member sits in (traverse_band_kernel tests it too)
-                const float *Q = &cs.nsubs[(size_t)(gpos[k] / rtc::SUBGROUP) * 4];
-                const float tq = fabsf(fmaf(Q[2], bz, fmaf(Q[1], by, Q[0] * bx)));
-                if ((tg < G[3] && tq < Q[3]) || wild) {
-                    gp++;
-                    const float *m = &cs.nrecs[(size_t)gpos[k] * 8];
-                    const float t = fmaf(m[2], bz, fmaf(m[1], by, m[0] * bx));
-                    const float hgt = fmaf(m[6], o[2], fmaf(m[5], o[1], fmaf(m[4], o[0], -m[3])));
-                    const bool inside = fmaxf(fabsf(t), fabsf(hgt)) < 1.0f;
-                    if (wild ? (m[3] != 2.0f) : inside) {
-                        mp++;
-                        rtf::TriRec rec;
-                        rtf::make_general_rec(X, Y, Z, &rec);
-                        to_exact = rtf::filter_general(rec.v, o[0], o[1], o[2], d[0] * gg, d[1] * gg, d[2] * gg) >= -1.0f;
+#pragma omp parallel reduction(+ : pairs, gp, mp, sp, reach_exact, acc, bad, wildn, bad_closest, cells_n, tests_n, hits_n)
+    {
+        std::vector<char> visited(n_tris, 0), band_exact(n_tris, 0);
+        std::vector<int> touched;
+#pragma omp for schedule(dynamic, 16)
+        for (int i = 0; i < n_rays; i++) {
+            const float *o = org + 3 * i, *d = dir + 3 * i;
+            // prepare_general
+            const float ocx = o[0] - center[0], ocy = o[1] - center[1], ocz = o[2] - center[2];
+            const float dist = sqrtf(ocx * ocx + ocy * ocy + ocz * ocz);
+            const float g0 = rtf::dir_scale(dist + 3.0f * radius, d[0], d[1], d[2]);
+            const float dd = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+            const float inv = 1.0f / sqrtf(dd);
+            const float bx = d[0] * inv, by = d[1] * inv, bz = d[2] * inv;
+            const float g = (dist <= 1.25f * radius && dd > 1e-30f && dd < 1e30f) ? g0 : -g0;
+            const bool wild = !(g > 0.0f);
+            const bool walks = g > 0.0f;
+            const float gg = fabsf(g);
+            wildn += wild;
+            // the walk that never stops: every triangle of every cell on the line
+            touched.clear();
+            if (walks) {
+                rtv::Walk w{};
+                if (rtv::walk_start(G, o[0], o[1], o[2], d[0], d[1], d[2], w)) {
+                    do {
+                        const int cell = rtv::cell_index(G, w);
+                        for (uint32_t e = vs.off[cell]; e < vs.off[cell + 1]; e++) {
+                            const int t = vs.entries[e];
+                            if (!visited[t]) { visited[t] = 1; touched.push_back(t); }
+                        }
+                    } while (rtv::walk_step(G, o[0], o[1], o[2], w));
+                }
+            }
+            float brute_t = INFINITY;
+            int brute_id = -1;
+            float model_t = INFINITY;
+            int model_id = -1;
+            for (int k = 0; k < n_tris; k++) {
+                const float *X = verts + 9 * k, *Y = X + 3, *Z = X + 6;
+                bool to_exact = false;
+                if (group_of[k] >= 0) {
+                    const float *Gr = &cs.ngroups[(size_t)group_of[k] * 4];
+                    const float tg = fabsf(fmaf(Gr[2], bz, fmaf(Gr[1], by, Gr[0] * bx)));
+                    // the part of the group the member sits in (traverse_band_kernel tests it too)
+                    const float *Q = &cs.nsubs[(size_t)(gpos[k] / rtc::SUBGROUP) * 4];
+                    const float tq = fabsf(fmaf(Q[2], bz, fmaf(Q[1], by, Q[0] * bx)));
+                    if ((tg < Gr[3] && tq < Q[3]) || wild) {
+                        gp++;
+                        const float *m = &cs.nrecs[(size_t)gpos[k] * 8];
+                        const float t = fmaf(m[2], bz, fmaf(m[1], by, m[0] * bx));
+                        const float hgt = fmaf(m[6], o[2], fmaf(m[5], o[1], fmaf(m[4], o[0], -m[3])));
+                        const bool inside = fmaxf(fabsf(t), fabsf(hgt)) < 1.0f;
+                        if (wild ? (m[3] != 2.0f) : inside) {
+                            mp++;
+                            to_exact = rtf::filter_general(grec[k].v, o[0], o[1], o[2], d[0] * gg, d[1] * gg, d[2] * gg) >= -1.0f;
+                        }
                     }
                 }
-            }
-            if (!to_exact && cluster_of[k] >= 0 && !wild) {
-                if (rtf::cluster_test(&cs.spheres[(size_t)cluster_of[k] * 4], o[0], o[1], o[2], bx, by, bz)) {
+                band_exact[k] = to_exact;
+                if (!to_exact && visited[k]) {
                     sp++;
-                    to_exact = rtf::filter_general(cs.recs[cpos[k]].v, o[0], o[1], o[2], d[0] * gg, d[1] * gg, d[2] * gg) >= -1.0f;
+                    to_exact = rtf::filter_general(grec[k].v, o[0], o[1], o[2], d[0] * gg, d[1] * gg, d[2] * gg) >= -1.0f;
                 }
+                float t;
+                const bool a = rto_ray_vs_triangle(o, d, X, Y, Z, &t) != 0 && t > 0.0f;
+                pairs++;
+                reach_exact += to_exact;
+                acc += a;
+                bad += (a && !to_exact);
+                if (a && t < brute_t) { brute_t = t; brute_id = k; } // the reference's sequential rule
+                if (a && band_exact[k] && (t < model_t || (t == model_t && k < model_id))) { model_t = t; model_id = k; }
             }
-            float t;
-            const bool a = rto_ray_vs_triangle(o, d, X, Y, Z, &t) != 0 && t > 0.0f;
-            pairs++;
-            reach_exact += to_exact;
-            acc += a;
-            bad += (a && !to_exact);
+            for (int t : touched) visited[t] = 0;
+            // the walk with the stopping rule
+            if (walks) {
+                rtv::Walk w{};
+                float tbest = INFINITY;
+                int idbest = -1;
+                if (rtv::walk_start(G, o[0], o[1], o[2], d[0], d[1], d[2], w)) {
+                    for (;;) {
+                        cells_n++;
+                        const int cell = rtv::cell_index(G, w);
+                        for (uint32_t e = vs.off[cell]; e < vs.off[cell + 1]; e++) {
+                            const int k = vs.entries[e];
+                            tests_n++;
+                            if (!(rtf::filter_general(grec[k].v, o[0], o[1], o[2], d[0] * gg, d[1] * gg, d[2] * gg) >= -1.0f))
+                                continue;
+                            float t;
+                            if (rto_ray_vs_triangle(o, d, verts + 9 * k, verts + 9 * k + 3, verts + 9 * k + 6, &t) != 0 &&
+                                t > 0.0f && (t < tbest || (t == tbest && k < idbest))) {
+                                tbest = t;
+                                idbest = k;
+                            }
+                        }
+                        if (!rtv::walk_step(G, o[0], o[1], o[2], w) || rtv::walk_done(G, w, tbest)) break;
+                    }
+                }
+                if (idbest >= 0 && (tbest < model_t || (tbest == model_t && idbest < model_id))) { model_t = tbest; model_id = idbest; }
+            }
+            hits_n += brute_id >= 0;
+            uint32_t tb, tm;
+            memcpy(&tb, &brute_t, 4);
+            memcpy(&tm, &model_t, 4);
+            bad_closest += (brute_id != model_id) || (tb != tm);
         }
     }
     stats[0] = pairs; stats[1] = gp; stats[2] = mp; stats[3] = sp; stats[4] = reach_exact; stats[5] = acc;
     stats[6] = bad; stats[7] = wildn; stats[8] = noclu; stats[9] = never;
+    stats[10] = bad_closest; stats[11] = cells_n; stats[12] = tests_n; stats[13] = hits_n;
 }
 
 // Cone of a run of 32 triangles (rt_filter.h make_cluster_cone) and the cone around four such cones

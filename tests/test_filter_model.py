@@ -334,20 +334,27 @@ def test_cone_cascade_wild_rays_fall_back_to_the_edge_filter(fm):
 
 
 # -- clustered traversal of arbitrary rays (normal groups + band/slab, spatial clusters) ---------
-CL_KEYS = ["pairs", "group", "member", "sphere", "to_exact", "accepts", "bad", "wild", "unclustered", "never"]
+CL_KEYS = ["pairs", "group", "member", "sphere", "to_exact", "accepts", "bad", "wild", "unclustered", "never",
+           "bad_closest", "cells", "tests", "hits"]
 
 
-def run_clustered(fm, tris, org, dirs, sphere=None):
+def run_clustered(fm, tris, org, dirs, sphere=None, voxel_res=0):
+    """`bad` counts pairs the oracle accepts that never reach the reference arithmetic (the walk over the
+    cells in space not stopping early); `bad_closest` counts rays whose closest hit differs from the
+    oracle's when the walk stops by its rule.  Both must be 0 (folded into "bad" for the callers)."""
     c, r = bounding_sphere(tris) if sphere is None else sphere
-    stats = (C.c_longlong * 10)()
+    stats = (C.c_longlong * 14)()
     tris = np.ascontiguousarray(tris, dtype=f32)
     org = np.ascontiguousarray(org, dtype=f32)
     dirs = np.ascontiguousarray(dirs, dtype=f32)
     fm.fm_check_clustered.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
-                                      C.c_void_p]
+                                      C.c_int, C.c_void_p]
     fm.fm_check_clustered(tris.shape[0], tris.ctypes.data, org.shape[0], org.ctypes.data, dirs.ctypes.data,
-                          c.ctypes.data, r, stats)
-    return dict(zip(CL_KEYS, list(stats)))
+                          c.ctypes.data, r, voxel_res, stats)
+    st = dict(zip(CL_KEYS, list(stats)))
+    st["bad_pairs"] = st["bad"]
+    st["bad"] = st["bad"] + st["bad_closest"]
+    return st
 
 
 def bounce_like_rays(rs, tris, n, extent, offset):
