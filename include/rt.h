@@ -167,7 +167,10 @@ int rt_set_option(rt_ctx *ctx, int option /* rt_option */, long long value);
  *   rt_raygen    = raygen_cs.glsl:1-22
  *   rt_intersect = rayintersect_cs.glsl:1-34 (+ trace.glsl:121-184)
  *   rt_color     = raycol_cs.glsl:18-128     (+ trace.glsl:121-184)
- * Asynchronous: they enqueue work on the context's stream and return. */
+ * Asynchronous: they enqueue work on the context's stream and return; how many rays are alive is
+ * counted and read on the device only.  One exception: the first rt_intersect after rt_set_camera
+ * moved the camera's position, and the first rt_color after rt_set_lights moved a light, rebuild that
+ * origin's triangle lists and wait for their sizes (a few stream synchronisations). */
 int rt_raygen(rt_ctx *ctx);
 int rt_intersect(rt_ctx *ctx);
 int rt_color(rt_ctx *ctx);

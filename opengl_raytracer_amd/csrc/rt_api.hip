@@ -146,10 +146,12 @@ struct rt_ctx {
     int *list = nullptr;    // compacted ray indices (live rays / rays with a finite origin)
     int *alist[2] = {nullptr, nullptr}; // shadow rays still unoccluded (slots), ping-pong
     // shadow rays sorted by the direction in which they leave the light
-    unsigned int *sort_keys = nullptr, *sort_keys_out = nullptr;
-    int *sort_iota = nullptr, *sort_slots = nullptr;
-    void *sort_temp = nullptr;
-    size_t sort_temp_bytes = 0;
+    unsigned int *sort_keys = nullptr;
+    int *sort_slots = nullptr;
+    // ... by counting: rays per key, their exclusive scan, rocprim's temporary storage for the scan
+    unsigned int *bin_hist_d = nullptr, *bin_off_d = nullptr;
+    void *bin_temp_d = nullptr;
+    size_t bin_temp_bytes = 0;
     int *count_d = nullptr; // [0] intersect list, [1] shade list, [2],[3] alist sizes
     int *count_h = nullptr; // pinned
     float *work = nullptr;  // per-slot planes behind job / scratch
@@ -189,7 +191,10 @@ struct rt_ctx {
     // kernel log: a ring of event pairs around the traversal launches
     static constexpr int KLOG = 1024;
     EventPair klog_ev[KLOG] = {};
-    rt_kernel_record klog_rec[KLOG] = {};
+    rt_kernel_record klog_rec[KLOG] = {}; // until read: rays = the count if known on the host, pairs = triangles per ray
+    int klog_nslot[KLOG] = {};            // entry of klog_n_d that holds the launch's ray count, or -1
+    int *klog_n_d = nullptr;              // list lengths, written by the stages' setup kernels
+    int n_slot_next = 0;
     size_t klog_count = 0; // launches logged since the last read
 
     std::string error;
@@ -350,17 +355,18 @@ extern "C" int rt_create(rt_ctx **out, int hip_device, int width, int height)
     CRCHK(hipMalloc(&c->alist[0], c->cap * sizeof(int)));
     CRCHK(hipMalloc(&c->alist[1], c->cap * sizeof(int)));
     CRCHK(hipMalloc(&c->sort_keys, c->cap * sizeof(unsigned int)));
-    CRCHK(hipMalloc(&c->sort_keys_out, c->cap * sizeof(unsigned int)));
-    CRCHK(hipMalloc(&c->sort_iota, c->cap * sizeof(int)));
     CRCHK(hipMalloc(&c->sort_slots, c->cap * sizeof(int)));
     {
-        std::vector<int> iota(c->cap);
-        for (size_t i = 0; i < c->cap; i++) iota[i] = (int)i;
-        CRCHK(hipMemcpy(c->sort_iota, iota.data(), c->cap * sizeof(int), hipMemcpyHostToDevice));
-        CRCHK(rocprim::radix_sort_pairs(nullptr, c->sort_temp_bytes, c->sort_keys, c->sort_keys_out, c->sort_iota,
-                                        c->sort_slots, c->cap, 0, 20));
-        CRCHK(hipMalloc(&c->sort_temp, c->sort_temp_bytes + 256));
+        // keys are direction cells of at most MAX_BITS bits per axis (plus one bin for the scan's total)
+        const size_t bins = ((size_t)1 << (2 * rtg::MAX_BITS)) + 1;
+        CRCHK(hipMalloc(&c->bin_hist_d, bins * sizeof(unsigned int)));
+        CRCHK(hipMalloc(&c->bin_off_d, bins * sizeof(unsigned int)));
+        CRCHK(rocprim::exclusive_scan(nullptr, c->bin_temp_bytes, c->bin_hist_d, c->bin_off_d, 0u, bins,
+                                      rocprim::plus<unsigned int>()));
+        CRCHK(hipMalloc(&c->bin_temp_d, c->bin_temp_bytes + 256));
     }
+    CRCHK(hipMalloc(&c->klog_n_d, rt_ctx::KLOG * sizeof(int)));
+    CRCHK(hipMemsetAsync(c->klog_n_d, 0, rt_ctx::KLOG * sizeof(int), c->stream));
     {
         // 7 + 4 job planes + 6 float scratch planes + lit + occ + best (two words per slot)
         const size_t planes = 7 + 4 + 6 + 1 + 1 + 2;
@@ -452,10 +458,11 @@ extern "C" void rt_destroy(rt_ctx *c)
     (void)hipFree(c->alist[0]);
     (void)hipFree(c->alist[1]);
     (void)hipFree(c->sort_keys);
-    (void)hipFree(c->sort_keys_out);
-    (void)hipFree(c->sort_iota);
     (void)hipFree(c->sort_slots);
-    (void)hipFree(c->sort_temp);
+    (void)hipFree(c->bin_hist_d);
+    (void)hipFree(c->bin_off_d);
+    (void)hipFree(c->bin_temp_d);
+    (void)hipFree(c->klog_n_d);
     (void)hipFree(c->cell_cones_d);
     (void)hipFree(c->grid_count_d);
     (void)hipFree(c->scan_temp);
@@ -889,8 +896,33 @@ extern "C" int rt_raygen(rt_ctx *c)
 }
 
 // ---- launch geometry ---------------------------------------------------------
-// rays per lane: more rays amortise each LDS record read over more arithmetic;
-// fewer rays give small launches enough lanes to spread over 256 CUs.
+// How many rays a stage has to trace is only known on the device (the compaction kernels count them),
+// and the host never waits for it: every kernel over a list reads the list's length itself, and its
+// launch has a number of workgroups that depends on the context's ray count alone -- enough for the
+// longest list there can be, capped at MAX_LIST_BLOCKS, each workgroup (or wavefront) taking every
+// n-th piece of the list.
+static int list_blocks(long long n_upper, int per_block)
+{
+    const long long b = (n_upper + per_block - 1) / per_block;
+    return (int)(b < 1 ? 1 : (b > MAX_LIST_BLOCKS ? MAX_LIST_BLOCKS : b));
+}
+
+// workgroups of a direction-cell kernel (four wavefronts of R rays, R chosen on the device from the
+// list's length n <= n_upper): enough for the n that needs the most
+static int wave_blocks(int n_upper)
+{
+    long long need = 1;
+    const int marks[4] = {n_upper, (1 << 16) - 1, (1 << 18) - 1, (1 << 21) - 1};
+    for (int m : marks) {
+        if (m > n_upper || m <= 0) continue;
+        const long long b = ((long long)m + (BLOCK / 64) * rays_per_wave_for(m) - 1) / ((BLOCK / 64) * rays_per_wave_for(m));
+        if (b > need) need = b;
+    }
+    return (int)need;
+}
+
+// rays per lane of the streaming kernels: more rays amortise each LDS record read over more
+// arithmetic; fewer rays give small launches enough lanes to spread over 256 CUs.
 static int pick_rays_per_lane(int n)
 {
     if (n >= 65536) return 4;
@@ -909,15 +941,16 @@ static int pick_tiles_per_y(int ray_blocks, int tiles)
     return (tiles + want_y - 1) / want_y;
 }
 
-static int pick_rays_per_wave(int n);
-
-static int klog_begin(rt_ctx *c, int stage, int form, int k, bool exact, unsigned long long rays,
-                      unsigned long long pairs, size_t *slot)
+// Kernel log.  The number of rays of a launch is taken from n_slot: the entry of klog_n_d into which
+// the stage's setup kernel wrote the length of its list (-1: fixed_rays, known on the host).
+static int klog_begin(rt_ctx *c, int stage, int form, int k, bool exact, int n_slot, unsigned long long fixed_rays,
+                      unsigned long long tris, size_t *slot)
 {
     *slot = c->klog_count % rt_ctx::KLOG;
     rt_kernel_record &r = c->klog_rec[*slot];
     r.stage = stage; r.form = form; r.rays_per_lane = k; r.exact = exact ? 1 : 0;
-    r.rays = rays; r.pairs = pairs; r.ms = 0.0f; r.reserved = 0.0f;
+    r.rays = fixed_rays; r.pairs = tris; r.ms = 0.0f; r.reserved = 0.0f;
+    c->klog_nslot[*slot] = n_slot;
     c->klog_count++;
     HIPCHK(c, hipEventRecord(c->klog_ev[*slot].a, c->stream));
     return RT_OK;
@@ -926,6 +959,12 @@ static int klog_end(rt_ctx *c, size_t slot)
 {
     HIPCHK(c, hipEventRecord(c->klog_ev[slot].b, c->stream));
     return RT_OK;
+}
+// the entry of klog_n_d the next setup kernel writes its list's length to
+static int next_n_slot(rt_ctx *c)
+{
+    c->n_slot_next = (c->n_slot_next + 1) % rt_ctx::KLOG;
+    return c->n_slot_next;
 }
 
 template <int K, int FORM, bool ANYHIT>
@@ -937,9 +976,10 @@ static void launch_traverse_k(rt_ctx *c, const TraverseParams &p, dim3 grid)
         hipLaunchKernelGGL((traverse_kernel<K, FORM, ANYHIT, false>), grid, dim3(BLOCK), 0, c->stream, p);
 }
 
-// One traversal launch: the rays of a list (at most n_upper of them) against the
-// triangles [tri_begin, tri_end).  stage: 1 closest hit, 2 shadow.
-static int launch_traverse(rt_ctx *c, TraverseParams p, int n_upper, int form, bool anyhit, int stage)
+// One launch of the streaming traversal: the rays of a list (at most n_upper of them) against the
+// triangles [tri_begin, tri_end).  stage: 1 closest hit, 2 shadow.  (Its workgroups are laid out for
+// n_upper rays; those beyond the list's end leave at once.)
+static int launch_traverse(rt_ctx *c, TraverseParams p, int n_upper, int n_slot, int form, bool anyhit, int stage)
 {
     const int k = pick_rays_per_lane(n_upper);
     const int ray_blocks = cdiv(n_upper, BLOCK * k);
@@ -952,8 +992,8 @@ static int launch_traverse(rt_ctx *c, TraverseParams p, int n_upper, int form, b
     if (p.tiles_per_y > (1 << 21) / TILE) p.tiles_per_y = (1 << 21) / TILE;
     const dim3 grid(ray_blocks, cdiv(tiles, p.tiles_per_y));
     size_t ks;
-    if (int r = klog_begin(c, stage, form, k, c->trace_mode == RT_TRACE_EXACT, (unsigned long long)n_upper,
-                           (unsigned long long)n_upper * (unsigned long long)(p.tri_end - p.tri_begin), &ks))
+    if (int r = klog_begin(c, stage, form, k, c->trace_mode == RT_TRACE_EXACT, n_slot, (unsigned long long)n_upper,
+                           (unsigned long long)(p.tri_end - p.tri_begin), &ks))
         return r;
 #define RT_DISPATCH(KK)                                                             \
     do {                                                                            \
@@ -969,24 +1009,39 @@ static int launch_traverse(rt_ctx *c, TraverseParams p, int n_upper, int form, b
     return klog_end(c, ks);
 }
 
-// The clustered closest-hit traversal of arbitrary rays (form 2 in the kernel log).  Large launches
-// run the two sweeps as two kernels over two orders of the same rays: the band sweep over rays sorted
-// by direction (a wavefront's rays then share the few groups whose band holds them), the sphere sweep
-// over the pixel-tile order (its rays pass the same clusters).  Both merge into `best` by atomicMin.
+// out = the slots 0 .. *count - 1 grouped by key (any order inside a key): count, scan, scatter.
+static int bin_slots(rt_ctx *c, const unsigned int *keys, const int *count, int n_upper, int key_bits, int *out)
+{
+    const size_t bins = ((size_t)1 << key_bits) + 1;
+    HIPCHK(c, hipMemsetAsync(c->bin_hist_d, 0, bins * sizeof(unsigned int), c->stream));
+    const dim3 grid(list_blocks(n_upper, BLOCK));
+    hipLaunchKernelGGL(bin_count_kernel, grid, dim3(BLOCK), 0, c->stream, keys, count, c->bin_hist_d);
+    HIPCHK(c, hipGetLastError());
+    size_t bytes = c->bin_temp_bytes;
+    HIPCHK(c, rocprim::exclusive_scan(c->bin_temp_d, bytes, c->bin_hist_d, c->bin_off_d, 0u, bins,
+                                      rocprim::plus<unsigned int>(), c->stream));
+    hipLaunchKernelGGL(bin_scatter_kernel, grid, dim3(BLOCK), 0, c->stream, keys, count,
+                       (const unsigned int *)c->bin_off_d, c->bin_hist_d, out);
+    HIPCHK(c, hipGetLastError());
+    return RT_OK;
+}
+
+// The clustered closest-hit traversal of arbitrary rays (form 2 in the kernel log): two kernels over two
+// orders of the same rays -- the band sweep over rays grouped by direction (a wavefront's rays then share
+// the few lists or groups whose band holds them), the walk over the cells in space in pixel-tile order
+// (neighbours start in the same cells).  Both merge into `best` by atomicMin.
 static bool sweeps_side_by_side(const rt_ctx *c) { return !c->sweeps_in_turn; }
 
 // Opens the kernel-log record of a clustered bounce pass and lets the side stream run from here on.
-static int fork_side_stream(rt_ctx *c, int n_upper, size_t *ks)
+static int fork_side_stream(rt_ctx *c, int n_slot, size_t *ks)
 {
-    if (int r = klog_begin(c, 1, 2, 1, false, (unsigned long long)n_upper,
-                           (unsigned long long)n_upper * (unsigned long long)c->num_tris, ks))
-        return r;
+    if (int r = klog_begin(c, 1, 2, 1, false, n_slot, 0ull, (unsigned long long)c->num_tris, ks)) return r;
     HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->stream_side, c->ev_fork, 0));
     return RT_OK;
 }
 
-static int launch_traverse_clustered(rt_ctx *c, TraverseParams p, int n_upper, bool sorted)
+static int launch_traverse_clustered(rt_ctx *c, TraverseParams p, int n_upper, int n_slot, bool sorted)
 {
     p.ngroups = c->ngroup_d;
     p.nsubs = c->nsub_d;
@@ -996,44 +1051,38 @@ static int launch_traverse_clustered(rt_ctx *c, TraverseParams p, int n_upper, b
     p.vox_off = c->vox_off_d;
     p.vox_entries = c->vox_entries_d;
     if (n_upper <= 0 || p.tri_end <= p.tri_begin) return RT_OK;
-    const unsigned long long pairs = (unsigned long long)n_upper * (unsigned long long)(p.tri_end - p.tri_begin);
+    const unsigned long long tris = (unsigned long long)(p.tri_end - p.tri_begin);
     size_t ks;
     // The two sweeps are two kernels that only meet in `best` (atomicMin).  With the band lists they run
     // side by side, the walk over the cells in space on the side stream, and the log holds one record for
     // the pair; otherwise one after the other, one record each (the second with 0 pairs).
     const bool fork = c->band_entries && sweeps_side_by_side(c);
     if (fork) {
-        // rt_intersect forks before it sorts the rays for the band sweep (the walk does not wait for the sort)
+        // rt_intersect forks before it groups the rays for the band sweep (the walk does not wait for that)
         if (c->forked) ks = c->forked_ks;
-        else if (int r = fork_side_stream(c, n_upper, &ks)) return r;
+        else if (int r = fork_side_stream(c, n_slot, &ks)) return r;
         c->forked = false;
-    } else if (int r = klog_begin(c, 1, 2, 1, false, (unsigned long long)n_upper, pairs, &ks)) {
+    } else if (int r = klog_begin(c, 1, 2, 1, false, n_slot, 0ull, tris, &ks)) {
         return r;
     }
     // ---- the band sweep: ill-conditioned pairs
     TraverseParams a = p;
-    if (sorted) {
-        // sorted rays share direction cells / groups; any order gives the same result
-        a.alist = c->sort_slots;
-        a.count = nullptr;
-        a.n = n_upper;
-    }
+    if (sorted) a.alist = c->sort_slots; // rays grouped by direction share cells / groups; any order gives the same result
     if (c->band_entries) {
         a.band_off = c->band_off;
         a.band_entries = c->band_entries;
         a.grid_bits = c->grid_bits;
-        a.rays_per_wave = pick_rays_per_wave(n_upper);
-        hipLaunchKernelGGL(traverse_bandcell_kernel, dim3(cdiv(n_upper, (BLOCK / 64) * a.rays_per_wave)), dim3(BLOCK), 0,
-                           c->stream, a);
+        a.rays_per_wave = 0; // from the list's length, on the device
+        hipLaunchKernelGGL(traverse_bandcell_kernel, dim3(wave_blocks(n_upper)), dim3(BLOCK), 0, c->stream, a);
     } else if (sorted) {
-        const int ray_blocks = cdiv(n_upper, BLOCK * 4);
+        const int ray_blocks = list_blocks(n_upper, BLOCK * 4);
         int want_y = (8192 + ray_blocks - 1) / ray_blocks;
         const int max_y = cdiv(c->num_ngroups, BAND_TILE_GROUPS);
         if (want_y > max_y) want_y = max_y;
         if (want_y < 1) want_y = 1;
         hipLaunchKernelGGL((traverse_band_kernel<4>), dim3(ray_blocks, want_y), dim3(BLOCK), 0, c->stream, a);
     } else {
-        const int ray_blocks = cdiv(n_upper, BLOCK);
+        const int ray_blocks = list_blocks(n_upper, BLOCK);
         int want_y = (8192 + ray_blocks - 1) / ray_blocks;
         const int max_y = cdiv(c->num_ngroups, GROUP_TILE);
         if (want_y > max_y) want_y = max_y;
@@ -1043,10 +1092,9 @@ static int launch_traverse_clustered(rt_ctx *c, TraverseParams p, int n_upper, b
     HIPCHK(c, hipGetLastError());
     if (!fork) {
         if (int r = klog_end(c, ks)) return r;
-        if (int r = klog_begin(c, 1, 2, 1, false, (unsigned long long)n_upper, 0ull, &ks)) return r;
+        if (int r = klog_begin(c, 1, 2, 1, false, n_slot, 0ull, 0ull, &ks)) return r;
     }
-    // ---- the walk over the cells in space: well-conditioned pairs (rays in pixel-tile order: neighbours
-    //      start in the same cells)
+    // ---- the walk over the cells in space: well-conditioned pairs
     hipLaunchKernelGGL(traverse_voxel_kernel, dim3(cdiv(n_upper, BLOCK)), dim3(BLOCK), 0,
                        fork ? c->stream_side : c->stream, p);
     HIPCHK(c, hipGetLastError());
@@ -1177,17 +1225,8 @@ static int build_grid(rt_ctx *c, int which, const rtf::ConeRec *cones, const rtf
     return RT_OK;
 }
 
-// Rays per wavefront of the direction-cell kernels: enough wavefronts to hide the list reads of each.
-static int pick_rays_per_wave(int n)
-{
-    if (n >= 1 << 21) return 64;
-    if (n >= 1 << 18) return 32;
-    if (n >= 1 << 16) return 16;
-    return 8;
-}
-
 // One launch of the direction-cell traversal over the rays of a list.  stage: 1 closest hit, 2 shadow.
-static int launch_traverse_grid(rt_ctx *c, TraverseParams p, int n_upper, int which, bool anyhit, int stage)
+static int launch_traverse_grid(rt_ctx *c, TraverseParams p, int n_upper, int n_slot, int which, bool anyhit, int stage)
 {
     if (n_upper <= 0) return RT_OK;
     p.grid_off = c->grid_off[which];
@@ -1195,11 +1234,10 @@ static int launch_traverse_grid(rt_ctx *c, TraverseParams p, int n_upper, int wh
     p.grid_bits = c->grid_bits;
     p.num_slots = c->num_slots;
     size_t ks;
-    if (int r = klog_begin(c, stage, 3, 1, false, (unsigned long long)n_upper,
-                           (unsigned long long)n_upper * (unsigned long long)c->num_tris, &ks))
+    if (int r = klog_begin(c, stage, 3, 1, false, n_slot, (unsigned long long)n_upper, (unsigned long long)c->num_tris, &ks))
         return r;
-    p.rays_per_wave = pick_rays_per_wave(n_upper);
-    const dim3 grid(cdiv(n_upper, (BLOCK / 64) * p.rays_per_wave));
+    p.rays_per_wave = p.count ? 0 : rays_per_wave_for(n_upper); // a device-side count: chosen there
+    const dim3 grid(p.count ? wave_blocks(n_upper) : cdiv(n_upper, (BLOCK / 64) * p.rays_per_wave));
     if (anyhit) hipLaunchKernelGGL((traverse_grid_kernel<true>), grid, dim3(BLOCK), 0, c->stream, p);
     else hipLaunchKernelGGL((traverse_grid_kernel<false>), grid, dim3(BLOCK), 0, c->stream, p);
     HIPCHK(c, hipGetLastError());
@@ -1253,15 +1291,6 @@ static int refresh_light_recs(rt_ctx *c)
     return RT_OK;
 }
 
-// reads count_d[which] back to the host (one 4-byte copy and a stream sync)
-static int read_count(rt_ctx *c, int which, int *out)
-{
-    HIPCHK(c, hipMemcpyAsync(c->count_h + which, c->count_d + which, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    *out = c->count_h[which];
-    return RT_OK;
-}
-
 static bool use_grid(const rt_ctx *c)
 {
     return c->grid_bits > 0 && c->trace_mode == RT_TRACE_CLUSTERED && c->num_slots > 0;
@@ -1294,83 +1323,91 @@ static void fill_traverse_common(rt_ctx *c, TraverseParams &p)
     p.counters = c->counters_d;
 }
 
+// Records the end of a stage's event pair when the stage call returns, whichever way it returns.
+struct StageScope {
+    rt_ctx *c;
+    size_t slot;
+    bool open = false;
+    ~StageScope()
+    {
+        if (open) (void)hipEventRecord(c->ev_pool[slot].b, c->stream);
+    }
+};
+
 extern "C" int rt_intersect(rt_ctx *c)
 {
     if (!c) return RT_ERR_ARG;
     if (int r = check_ready(c, true, true, "rt_intersect")) return r;
-    size_t slot;
-    if (int r = stage_begin(c, 1, &slot)) return r;
+    StageScope scope{c, 0};
+    if (int r = stage_begin(c, 1, &scope.slot)) return r;
+    scope.open = true;
     if (c->n_rays > 0) {
         const bool shared = c->rays_share_camera_origin;
         const int *list = nullptr, *count = nullptr;
-        int n_upper = c->n_rays;
+        const int n_upper = c->n_rays; // the live rays are counted on the device; the host does not wait for it
+        int n_slot = -1;
         if (shared) {
             // fresh rays: all live, all through camera_pos; visited in pixel-tile order
             if (int r = refresh_camera_recs(c)) return r;
             list = c->perm_d;
         } else {
             HIPCHK(c, hipMemsetAsync(c->count_d, 0, sizeof(int), c->stream));
-            hipLaunchKernelGGL((compact_kernel<0>), dim3(cdiv(c->n_rays, BLOCK * COMPACT_ITERS)), dim3(BLOCK), 0,
+            hipLaunchKernelGGL((compact_kernel<0>), dim3(list_blocks(c->n_rays, BLOCK * COMPACT_ITERS)), dim3(BLOCK), 0,
                                c->stream, c->rays, (const int *)c->perm_d, (const int *)nullptr, (const int *)nullptr,
                                c->n_rays, (const int *)nullptr, c->list, c->count_d, (uint32_t *)nullptr);
             HIPCHK(c, hipGetLastError());
-            if (int r = read_count(c, 0, &n_upper)) return r;
             list = c->list;
             count = c->count_d;
+            n_slot = next_n_slot(c);
         }
-        if (n_upper > 0) {
-            // a few hundred triangles are streamed through the per-pair filter faster than their groups
-            // are swept
-            // (the group sweeps queue pairs as triangle * 2048 + ray in 32 bits: larger meshes take it too)
-            const bool clustered = !shared && c->trace_mode == RT_TRACE_CLUSTERED &&
-                                   c->num_tris >= c->cluster_min_tris && c->num_tris < (1 << 21);
-            const bool sorted = clustered && n_upper >= c->sort_min_rays && c->num_ngroups >= 64;
-            hipLaunchKernelGGL(intersect_setup_kernel, dim3(cdiv(n_upper, BLOCK)), dim3(BLOCK), 0, c->stream, c->rays,
-                               list, count, n_upper, c->job, c->scratch.best, shared ? 1 : (clustered ? 2 : 0),
-                               shared_origin(c, c->cam.pos, 1.0f), sorted ? c->sort_keys : (unsigned int *)nullptr);
-            HIPCHK(c, hipGetLastError());
-            c->forked = false;
-            if (clustered && c->band_entries && sweeps_side_by_side(c)) {
-                if (int r = fork_side_stream(c, n_upper, &c->forked_ks)) return r;
-                c->forked = true;
-            }
-            if (sorted) {
-                size_t bytes = c->sort_temp_bytes;
-                HIPCHK(c, rocprim::radix_sort_pairs(c->sort_temp, bytes, c->sort_keys, c->sort_keys_out, c->sort_iota,
-                                                    c->sort_slots, (size_t)n_upper, 0, sort_key_bits(c), c->stream));
-            }
-            TraverseParams p{};
-            fill_traverse_common(c, p);
-            p.alist = nullptr;
-            p.count = count;
-            p.n = n_upper;
-            p.recs = shared ? c->rec_camera : c->rec_general;
-            p.mrecs = c->rec_moment;
-            p.cones = c->cone_camera;
-            const bool exact = c->trace_mode == RT_TRACE_EXACT;
-            // shared origin: the records are in slot order; the all-pairs mode walks the mesh itself
-            p.tri_of = (shared && !exact) ? c->slot_d : nullptr;
-            p.ccones = (shared && c->trace_mode == RT_TRACE_CLUSTERED) ? c->ccone_camera : nullptr;
-            p.scones = p.ccones ? c->ccone_camera + c->scone_offset : nullptr;
-            p.reach_max = (float)rtf::cone_reach_max(c->cam.pos, c->center, c->radius);
-            p.dir_sign = 1.0f;
-            memcpy(p.origin, c->cam.pos, sizeof p.origin);
-            p.tri_begin = 0;
-            p.tri_end = (shared && !exact) ? c->num_slots : c->num_tris;
-            if (clustered) {
-                if (int r = launch_traverse_clustered(c, p, n_upper, sorted)) return r;
-            } else if (shared && use_grid(c)) {
-                if (int r = launch_traverse_grid(c, p, n_upper, 0, false, 1)) return r;
-            } else if (int r = launch_traverse(c, p, n_upper, shared ? 1 : 0, false, 1)) {
-                return r;
-            }
-            hipLaunchKernelGGL(intersect_finish_kernel, dim3(cdiv(n_upper, BLOCK)), dim3(BLOCK), 0, c->stream,
-                               c->rays, list, count, n_upper, c->job, c->scratch.best, c->verts, c->num_tris, c->cam,
-                               c->depth, c->counters_d);
-            HIPCHK(c, hipGetLastError());
+        // a few hundred triangles are streamed through the per-pair filter faster than their groups
+        // are swept
+        // (the group sweeps queue pairs as triangle * 2048 + ray in 32 bits: larger meshes take it too)
+        const bool clustered = !shared && c->trace_mode == RT_TRACE_CLUSTERED &&
+                               c->num_tris >= c->cluster_min_tris && c->num_tris < (1 << 21);
+        const bool sorted = clustered && n_upper >= c->sort_min_rays && c->num_ngroups >= 64;
+        hipLaunchKernelGGL(intersect_setup_kernel, dim3(list_blocks(n_upper, BLOCK)), dim3(BLOCK), 0, c->stream, c->rays,
+                           list, count, n_upper, c->job, c->scratch.best, shared ? 1 : (clustered ? 2 : 0),
+                           shared_origin(c, c->cam.pos, 1.0f), sorted ? c->sort_keys : (unsigned int *)nullptr,
+                           n_slot >= 0 ? c->klog_n_d + n_slot : (int *)nullptr);
+        HIPCHK(c, hipGetLastError());
+        c->forked = false;
+        if (clustered && c->band_entries && sweeps_side_by_side(c)) {
+            if (int r = fork_side_stream(c, n_slot, &c->forked_ks)) return r;
+            c->forked = true;
         }
+        if (sorted)
+            if (int r = bin_slots(c, c->sort_keys, count, n_upper, sort_key_bits(c), c->sort_slots)) return r;
+        TraverseParams p{};
+        fill_traverse_common(c, p);
+        p.alist = nullptr;
+        p.count = count;
+        p.n = n_upper;
+        p.recs = shared ? c->rec_camera : c->rec_general;
+        p.mrecs = c->rec_moment;
+        p.cones = c->cone_camera;
+        const bool exact = c->trace_mode == RT_TRACE_EXACT;
+        // shared origin: the records are in slot order; the all-pairs mode walks the mesh itself
+        p.tri_of = (shared && !exact) ? c->slot_d : nullptr;
+        p.ccones = (shared && c->trace_mode == RT_TRACE_CLUSTERED) ? c->ccone_camera : nullptr;
+        p.scones = p.ccones ? c->ccone_camera + c->scone_offset : nullptr;
+        p.reach_max = (float)rtf::cone_reach_max(c->cam.pos, c->center, c->radius);
+        p.dir_sign = 1.0f;
+        memcpy(p.origin, c->cam.pos, sizeof p.origin);
+        p.tri_begin = 0;
+        p.tri_end = (shared && !exact) ? c->num_slots : c->num_tris;
+        if (clustered) {
+            if (int r = launch_traverse_clustered(c, p, n_upper, n_slot, sorted)) return r;
+        } else if (shared && use_grid(c)) {
+            if (int r = launch_traverse_grid(c, p, n_upper, n_slot, 0, false, 1)) return r;
+        } else if (int r = launch_traverse(c, p, n_upper, n_slot, shared ? 1 : 0, false, 1)) {
+            return r;
+        }
+        hipLaunchKernelGGL(intersect_finish_kernel, dim3(list_blocks(n_upper, BLOCK)), dim3(BLOCK), 0, c->stream,
+                           c->rays, list, count, n_upper, c->job, c->scratch.best, c->verts, c->num_tris, c->cam,
+                           c->depth, c->counters_d);
+        HIPCHK(c, hipGetLastError());
     }
-    if (int r = stage_end(c, slot)) return r;
     c->hits_follow_pixels = c->rays_share_camera_origin;
     c->rays_share_camera_origin = false;
     return RT_OK;
@@ -1389,105 +1426,100 @@ extern "C" int rt_color(rt_ctx *c)
 {
     if (!c) return RT_ERR_ARG;
     if (int r = check_ready(c, true, true, "rt_color")) return r;
-    size_t slot;
-    if (int r = stage_begin(c, 2, &slot)) return r;
+    StageScope scope{c, 0};
+    if (int r = stage_begin(c, 2, &scope.slot)) return r;
+    scope.open = true;
     if (c->n_rays > 0) {
         if (c->num_lights == 0) {
             // no light: `shadowed` stays true for every pixel (raycol_cs.glsl:28-32, 82)
-            hipLaunchKernelGGL(fill_grey_kernel, dim3(cdiv(c->n_rays, BLOCK)), dim3(BLOCK), 0, c->stream, c->fb,
+            hipLaunchKernelGGL(fill_grey_kernel, dim3(list_blocks(c->n_rays, BLOCK)), dim3(BLOCK), 0, c->stream, c->fb,
                                c->n_rays);
             HIPCHK(c, hipGetLastError());
         } else {
             if (int r = refresh_light_recs(c)) return r;
             HIPCHK(c, hipMemsetAsync(c->count_d + 1, 0, sizeof(int), c->stream));
-            hipLaunchKernelGGL((compact_kernel<1>), dim3(cdiv(c->n_rays, BLOCK * COMPACT_ITERS)), dim3(BLOCK), 0,
+            hipLaunchKernelGGL((compact_kernel<1>), dim3(list_blocks(c->n_rays, BLOCK * COMPACT_ITERS)), dim3(BLOCK), 0,
                                c->stream, c->rays, (const int *)c->perm_d, (const int *)nullptr, (const int *)nullptr,
                                c->n_rays, (const int *)nullptr, c->list, c->count_d + 1, c->fb);
             HIPCHK(c, hipGetLastError());
-            int n0 = 0;
-            if (int r = read_count(c, 1, &n0)) return r;
-            if (n0 > 0) {
-                const int *cnt0 = c->count_d + 1;
-                const dim3 g0(cdiv(n0, BLOCK));
-                hipLaunchKernelGGL(color_begin_kernel, g0, dim3(BLOCK), 0, c->stream, c->rays, c->list, cnt0,
-                                   c->scratch);
+            // the rays with a finite origin are counted on the device; the host does not wait for it
+            const int n0 = c->n_rays;
+            const int *cnt0 = c->count_d + 1;
+            const dim3 g0(list_blocks(n0, BLOCK));
+            hipLaunchKernelGGL(color_begin_kernel, g0, dim3(BLOCK), 0, c->stream, c->rays, c->list, cnt0, c->scratch);
+            HIPCHK(c, hipGetLastError());
+            const bool exact = c->trace_mode == RT_TRACE_EXACT;
+            const int n_trav = exact ? c->num_tris : c->num_slots; // slots, or triangles in the all-pairs mode
+            const int chunk = shadow_chunk_tris(n_trav);
+            for (int a = 0; a < c->num_lights; a++) {
+                // in the clustered mode the shadow rays are visited in the order of the direction in
+                // which they leave the light (any order gives the same result)
+                const bool sorted = c->trace_mode == RT_TRACE_CLUSTERED && n0 >= c->sort_min_rays &&
+                                    c->num_slots >= 8192 && !(use_grid(c) && c->hits_follow_pixels);
+                const int n_slot = next_n_slot(c);
+                hipLaunchKernelGGL(shadow_setup_kernel, g0, dim3(BLOCK), 0, c->stream, cnt0, c->scratch, c->job,
+                                   c->lights[a].pos[0], c->lights[a].pos[1], c->lights[a].pos[2],
+                                   shared_origin(c, c->lights[a].pos, -1.0f), c->counters_d,
+                                   sorted ? c->sort_keys : (unsigned int *)nullptr, c->klog_n_d + n_slot);
                 HIPCHK(c, hipGetLastError());
-                const bool exact = c->trace_mode == RT_TRACE_EXACT;
-                const int n_trav = exact ? c->num_tris : c->num_slots; // slots, or triangles in the all-pairs mode
-                const int chunk = shadow_chunk_tris(n_trav);
-                for (int a = 0; a < c->num_lights; a++) {
-                    // in the clustered mode the shadow rays are visited in the order of the direction in
-                    // which they leave the light (any order gives the same result)
-                    const bool sorted = c->trace_mode == RT_TRACE_CLUSTERED && n0 >= c->sort_min_rays &&
-                                        c->num_slots >= 8192 && !(use_grid(c) && c->hits_follow_pixels);
-                    hipLaunchKernelGGL(shadow_setup_kernel, g0, dim3(BLOCK), 0, c->stream, cnt0, c->scratch, c->job,
-                                       c->lights[a].pos[0], c->lights[a].pos[1], c->lights[a].pos[2],
-                                       shared_origin(c, c->lights[a].pos, -1.0f), c->counters_d,
-                                       sorted ? c->sort_keys : (unsigned int *)nullptr);
-                    HIPCHK(c, hipGetLastError());
-                    const int *alist = nullptr; // nullptr: slots 0..n0-1
-                    if (sorted) {
-                        size_t bytes = c->sort_temp_bytes;
-                        HIPCHK(c, rocprim::radix_sort_pairs(c->sort_temp, bytes, c->sort_keys, c->sort_keys_out,
-                                                            c->sort_iota, c->sort_slots, (size_t)n0, 0, sort_key_bits(c), c->stream));
-                        alist = c->sort_slots;
-                    }
-                    const int *acount = cnt0;
-                    int pp = 0;
-                    if (use_grid(c)) {
-                        TraverseParams p{};
-                        fill_traverse_common(c, p);
-                        p.alist = alist;
-                        p.count = acount;
-                        p.n = n0;
-                        p.recs = c->rec_lights + (size_t)a * c->rec_stride;
-                        p.tri_of = c->slot_d;
-                        if (int r = launch_traverse_grid(c, p, n0, 1 + a, true, 2)) return r;
-                    }
-                    for (int t0 = 0; t0 < n_trav && !use_grid(c); t0 += chunk) {
-                        TraverseParams p{};
-                        fill_traverse_common(c, p);
-                        p.alist = alist;
-                        p.count = acount;
-                        p.n = n0;
-                        p.recs = c->rec_lights + (size_t)a * c->rec_stride;
-                        p.cones = c->cone_lights + (size_t)a * c->rec_stride;
-                        p.tri_of = exact ? nullptr : c->slot_d;
-                        p.ccones = c->trace_mode == RT_TRACE_CLUSTERED ? c->ccone_lights + (size_t)a * c->ccone_stride
-                                                                       : nullptr;
-                        p.scones = p.ccones ? p.ccones + c->scone_offset : nullptr;
-                        p.reach_max = (float)rtf::cone_reach_max(c->lights[a].pos, c->center, c->radius);
-                        p.dir_sign = -1.0f;
-                        memcpy(p.origin, c->lights[a].pos, sizeof p.origin);
-                        p.tri_begin = t0;
-                        p.tri_end = (t0 + chunk < n_trav) ? t0 + chunk : n_trav;
-                        if (int r = launch_traverse(c, p, n0, 1, true, 2)) return r;
-                        if (p.tri_end < n_trav) {
-                            // keep the rays that are still unoccluded for the next chunk
-                            int *ocount = c->count_d + 2 + pp;
-                            HIPCHK(c, hipMemsetAsync(ocount, 0, sizeof(int), c->stream));
-                            hipLaunchKernelGGL((compact_kernel<2>), dim3(cdiv(n0, BLOCK * COMPACT_ITERS)),
-                                               dim3(BLOCK), 0, c->stream, c->rays, (const int *)nullptr, alist, acount, n0,
-                                               (const int *)c->scratch.occ, c->alist[pp], ocount, (uint32_t *)nullptr);
-                            HIPCHK(c, hipGetLastError());
-                            alist = c->alist[pp];
-                            acount = ocount;
-                            pp ^= 1;
-                        }
-                    }
-                    hipLaunchKernelGGL(shadow_finish_kernel, g0, dim3(BLOCK), 0, c->stream, c->rays,
-                                       (const int *)c->list, alist, acount, n0, c->scratch, c->job, c->lights[a],
-                                       c->cam);
-                    HIPCHK(c, hipGetLastError());
+                const int *alist = nullptr; // nullptr: slots 0..n-1
+                if (sorted) {
+                    if (int r = bin_slots(c, c->sort_keys, cnt0, n0, sort_key_bits(c), c->sort_slots)) return r;
+                    alist = c->sort_slots;
                 }
-                hipLaunchKernelGGL(color_finish_kernel, g0, dim3(BLOCK), 0, c->stream, c->rays, (const int *)c->list,
-                                   cnt0, c->scratch, c->verts, c->num_vertices, (const uint32_t *)c->tex, c->tex_w,
-                                   c->tex_h, c->fb);
+                const int *acount = cnt0;
+                int pp = 0;
+                if (use_grid(c)) {
+                    TraverseParams p{};
+                    fill_traverse_common(c, p);
+                    p.alist = alist;
+                    p.count = acount;
+                    p.n = n0;
+                    p.recs = c->rec_lights + (size_t)a * c->rec_stride;
+                    p.tri_of = c->slot_d;
+                    if (int r = launch_traverse_grid(c, p, n0, n_slot, 1 + a, true, 2)) return r;
+                }
+                for (int t0 = 0; t0 < n_trav && !use_grid(c); t0 += chunk) {
+                    TraverseParams p{};
+                    fill_traverse_common(c, p);
+                    p.alist = alist;
+                    p.count = acount;
+                    p.n = n0;
+                    p.recs = c->rec_lights + (size_t)a * c->rec_stride;
+                    p.cones = c->cone_lights + (size_t)a * c->rec_stride;
+                    p.tri_of = exact ? nullptr : c->slot_d;
+                    p.ccones = c->trace_mode == RT_TRACE_CLUSTERED ? c->ccone_lights + (size_t)a * c->ccone_stride
+                                                                   : nullptr;
+                    p.scones = p.ccones ? p.ccones + c->scone_offset : nullptr;
+                    p.reach_max = (float)rtf::cone_reach_max(c->lights[a].pos, c->center, c->radius);
+                    p.dir_sign = -1.0f;
+                    memcpy(p.origin, c->lights[a].pos, sizeof p.origin);
+                    p.tri_begin = t0;
+                    p.tri_end = (t0 + chunk < n_trav) ? t0 + chunk : n_trav;
+                    if (int r = launch_traverse(c, p, n0, n_slot, 1, true, 2)) return r;
+                    if (p.tri_end < n_trav) {
+                        // keep the rays that are still unoccluded for the next chunk
+                        int *ocount = c->count_d + 2 + pp;
+                        HIPCHK(c, hipMemsetAsync(ocount, 0, sizeof(int), c->stream));
+                        hipLaunchKernelGGL((compact_kernel<2>), dim3(list_blocks(n0, BLOCK * COMPACT_ITERS)),
+                                           dim3(BLOCK), 0, c->stream, c->rays, (const int *)nullptr, alist, acount, n0,
+                                           (const int *)c->scratch.occ, c->alist[pp], ocount, (uint32_t *)nullptr);
+                        HIPCHK(c, hipGetLastError());
+                        alist = c->alist[pp];
+                        acount = ocount;
+                        pp ^= 1;
+                    }
+                }
+                hipLaunchKernelGGL(shadow_finish_kernel, g0, dim3(BLOCK), 0, c->stream, c->rays,
+                                   (const int *)c->list, alist, acount, n0, c->scratch, c->job, c->lights[a], c->cam);
                 HIPCHK(c, hipGetLastError());
             }
+            hipLaunchKernelGGL(color_finish_kernel, g0, dim3(BLOCK), 0, c->stream, c->rays, (const int *)c->list, cnt0,
+                               c->scratch, c->verts, c->num_vertices, (const uint32_t *)c->tex, c->tex_w, c->tex_h,
+                               c->fb);
+            HIPCHK(c, hipGetLastError());
         }
     }
-    if (int r = stage_end(c, slot)) return r;
     // a killed ray keeps its shifted origin: the rays no longer share an origin
     c->rays_share_camera_origin = false;
     c->hits_follow_pixels = false;
@@ -1612,12 +1644,16 @@ extern "C" int rt_kernel_log(rt_ctx *c, rt_kernel_record *out, int max, int *n)
     if (!c || !n || (max > 0 && !out)) return RT_ERR_ARG;
     if (int r = use_device(c)) return r;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<int> n_h(rt_ctx::KLOG);
+    HIPCHK(c, hipMemcpy(n_h.data(), c->klog_n_d, rt_ctx::KLOG * sizeof(int), hipMemcpyDeviceToHost));
     const size_t have = c->klog_count < (size_t)rt_ctx::KLOG ? c->klog_count : (size_t)rt_ctx::KLOG;
     const size_t first = c->klog_count - have;
     int w = 0;
     for (size_t i = first; i < c->klog_count && w < max; i++) {
         const size_t slot = i % rt_ctx::KLOG;
         rt_kernel_record r = c->klog_rec[slot];
+        if (c->klog_nslot[slot] >= 0) r.rays = (unsigned long long)n_h[c->klog_nslot[slot]];
+        r.pairs = r.rays * r.pairs; // triangles per ray until now
         HIPCHK(c, hipEventElapsedTime(&r.ms, c->klog_ev[slot].a, c->klog_ev[slot].b));
         out[w++] = r;
     }

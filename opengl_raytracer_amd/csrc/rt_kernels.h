@@ -231,8 +231,8 @@ __global__ __launch_bounds__(BLOCK) void compact_kernel(RaySoA r, const int *__r
     __shared__ int s_base;
     const int n = in_count ? *in_count : n_fixed;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int chunk = blockIdx.x * (BLOCK * COMPACT_ITERS);
-    if (chunk >= n) return;
+    // the launch has a fixed number of workgroups; each takes every gridDim.x-th chunk
+    for (int chunk = blockIdx.x * (BLOCK * COMPACT_ITERS); chunk < n; chunk += (int)gridDim.x * (BLOCK * COMPACT_ITERS)) {
     unsigned long long masks[COMPACT_ITERS];
     int value[COMPACT_ITERS];
 #pragma unroll
@@ -280,12 +280,29 @@ __global__ __launch_bounds__(BLOCK) void compact_kernel(RaySoA r, const int *__r
         const unsigned long long m = masks[it];
         if ((m >> lane) & 1ull) out[base + s_cnt[it][wave] + __popcll(m & lt)] = value[it];
     }
+    __syncthreads(); // s_cnt and s_base are reused by the next chunk
+    }
 }
 
 __global__ void fill_grey_kernel(uint32_t *__restrict__ fb, int n)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) fb[i] = 0xff1a1a1au;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) fb[i] = 0xff1a1a1au;
+}
+
+// Launches over compacted lists have a fixed number of workgroups (the length of a list is only known
+// on the device): thread t takes entries t, t + T, t + 2T, ... of the list, T threads in all.
+constexpr int MAX_LIST_BLOCKS = 8192;
+#define RT_FOR_EACH_SLOT(slot, n) \
+    for (int slot = blockIdx.x * BLOCK + threadIdx.x; slot < (n); slot += (int)gridDim.x * BLOCK)
+
+// Rays per wavefront of the direction-cell kernels, from the number of rays of the launch: enough
+// wavefronts to hide the list reads of each.
+__host__ __device__ inline int rays_per_wave_for(int n)
+{
+    if (n >= 1 << 21) return 64;
+    if (n >= 1 << 18) return 32;
+    if (n >= 1 << 16) return 16;
+    return 8;
 }
 
 // ---------------------------------------------------------------------------
@@ -353,6 +370,13 @@ constexpr unsigned long long BEST_NONE = 0x7f80000000000000ull; // t = +inf, ind
 // true iff the predicate holds in any lane of the wavefront (one v_cmp + a scalar test)
 __device__ __forceinline__ bool any64(bool b) { return __builtin_amdgcn_ballot_w64(b) != 0ull; }
 
+// number of set bits of `mask` below this lane
+__device__ __forceinline__ int lanes_below(unsigned long long mask)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32),
+                                          __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
+}
+
 __device__ __forceinline__ v3 vpos(const rt_vertex *__restrict__ v, int i)
 {
     const float4 p = *reinterpret_cast<const float4 *>(v + i);
@@ -366,11 +390,11 @@ __device__ __forceinline__ v3 vpos(const rt_vertex *__restrict__ v, int i)
 __global__ __launch_bounds__(BLOCK) void intersect_setup_kernel(RaySoA r, const int *__restrict__ list,
                                                                 const int *__restrict__ count, int n_fixed, Job job,
                                                                 unsigned long long *__restrict__ best, int shared,
-                                                                SharedOrigin so, unsigned int *keys)
+                                                                SharedOrigin so, unsigned int *keys, int *n_out)
 {
     const int n = count ? *count : n_fixed;
-    const int slot = blockIdx.x * BLOCK + threadIdx.x;
-    if (slot >= n) return;
+    if (n_out && blockIdx.x == 0 && threadIdx.x == 0) *n_out = n; // for the kernel log
+    RT_FOR_EACH_SLOT(slot, n) {
     const int i = list ? list[slot] : slot;
     v3 o = rtx::V(r.ox[i], r.oy[i], r.oz[i]);
     const v3 d = rtx::V(r.dx[i], r.dy[i], r.dz[i]);
@@ -383,6 +407,60 @@ __global__ __launch_bounds__(BLOCK) void intersect_setup_kernel(RaySoA r, const 
     if (keys) {
         // the cell under which the band sweep files the ray (rt_grid.h)
         keys[slot] = rtg::oct_cell_folded(d.x, d.y, d.z, so.key_bits);
+    }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Rays grouped by a key (the direction cell in which a list files them): out[] = the slots 0..n-1
+// ordered by key, in any order inside a key.  Count per key, exclusive scan (rocprim), scatter with
+// one atomic per ray; n is read on the device.  hist[] must be zero before the count and is zero
+// again after the scatter.
+// ---------------------------------------------------------------------------
+// (Rays of a wavefront often share a key -- neighbouring pixels, one cell -- and atomics on one address are
+// served one after the other: a wavefront issues one atomic per distinct key, on behalf of all its lanes.)
+__global__ __launch_bounds__(BLOCK) void bin_count_kernel(const unsigned int *__restrict__ keys,
+                                                          const int *__restrict__ count, unsigned int *__restrict__ hist)
+{
+    const int n = *count;
+    const int lane = threadIdx.x & 63;
+    for (int base = blockIdx.x * BLOCK; base < n; base += (int)gridDim.x * BLOCK) {
+        const int slot = base + threadIdx.x;
+        const bool valid = slot < n;
+        const unsigned int key = valid ? keys[slot] : 0xffffffffu;
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(valid);
+        while (todo) {
+            const int leader = __builtin_ctzll(todo);
+            const unsigned int k0 = (unsigned int)__builtin_amdgcn_readlane((int)key, leader);
+            const unsigned long long same = __builtin_amdgcn_ballot_w64(key == k0) & todo;
+            if (lane == leader) atomicAdd(&hist[k0], (unsigned int)__popcll(same));
+            todo &= ~same;
+        }
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void bin_scatter_kernel(const unsigned int *__restrict__ keys,
+                                                            const int *__restrict__ count,
+                                                            const unsigned int *__restrict__ off,
+                                                            unsigned int *__restrict__ hist, int *__restrict__ out)
+{
+    const int n = *count;
+    const int lane = threadIdx.x & 63;
+    for (int base = blockIdx.x * BLOCK; base < n; base += (int)gridDim.x * BLOCK) {
+        const int slot = base + threadIdx.x;
+        const bool valid = slot < n;
+        const unsigned int key = valid ? keys[slot] : 0xffffffffu;
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(valid);
+        while (todo) {
+            const int leader = __builtin_ctzll(todo);
+            const unsigned int k0 = (unsigned int)__builtin_amdgcn_readlane((int)key, leader);
+            const unsigned long long same = __builtin_amdgcn_ballot_w64(key == k0) & todo;
+            unsigned int first = 0;
+            if (lane == leader) first = atomicSub(&hist[k0], (unsigned int)__popcll(same)) - (unsigned int)__popcll(same);
+            first = (unsigned int)__builtin_amdgcn_readlane((int)first, leader);
+            if (key == k0 && valid) out[off[k0] + first + (unsigned int)lanes_below(same)] = slot;
+            todo &= ~same;
+        }
     }
 }
 
@@ -493,12 +571,6 @@ __device__ __forceinline__ float readlane_f(float v, int src)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
 }
 
-// number of set bits of `mask` below this lane
-__device__ __forceinline__ int lanes_below(unsigned long long mask)
-{
-    return (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32),
-                                          __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
-}
 
 // The shared-origin form is latency-bound in its run and queue handling: six wavefronts per SIMD
 // (80 VGPRs, a handful of spills) beat the four the register allocator would settle for.
@@ -1119,14 +1191,16 @@ __global__ __launch_bounds__(BLOCK) void traverse_grid_kernel(TraverseParams p)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = p.count ? *p.count : p.n;
-    const int R = p.rays_per_wave;
-    const int s0 = (blockIdx.x * (BLOCK / 64) + wave) * R;
-    const int s = s0 + lane;
-    if (s0 >= n) return; // the whole wavefront; no barriers below
+    const int R = p.rays_per_wave > 0 ? p.rays_per_wave : rays_per_wave_for(n);
     unsigned long long *best = best_all + (ANYHIT ? 0 : wave * 64);
     int *occl = occ_all + (ANYHIT ? wave * 64 : 0);
     float4 *ray_o = ray_o_all + wave * 64, *ray_d = ray_d_all + wave * 64;
     unsigned int *queue = queue_all + wave * GRID_QCAP;
+    // (the launch is laid out for the longest list there can be: wavefronts beyond the list's end leave at
+    // once; a loop over groups here would cost the registers of an eighth wavefront per SIMD)
+    const int s0 = (blockIdx.x * (BLOCK / 64) + wave) * R;
+    if (s0 >= n) return; // the whole wavefront; no barriers below
+    const int s = s0 + lane;
 
     bool valid = lane < R && s < n;
     const int sl = valid ? (p.alist ? p.alist[s] : s) : 0;
@@ -1296,10 +1370,11 @@ __global__ __launch_bounds__(BLOCK) void traverse_group_kernel(TraverseParams p)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = p.count ? *p.count : p.n;
-    const int s0 = blockIdx.x * NR;
-    if (s0 >= n) return;
     const int g_per_y = (p.num_ngroups + (int)gridDim.y - 1) / (int)gridDim.y;
     const int g_begin = blockIdx.y * g_per_y, g_end = min(g_begin + g_per_y, p.num_ngroups);
+    // a fixed number of workgroups along x: each takes every gridDim.x-th block of 256 rays
+    for (int s0 = blockIdx.x * NR; s0 < n; s0 += (int)gridDim.x * NR) {
+    __syncthreads(); // the staged rays of the previous block are no longer read
 
     const float qn = __int_as_float(0x7fc00000);
     const int r_own = wave * 64 + lane;
@@ -1430,6 +1505,7 @@ __global__ __launch_bounds__(BLOCK) void traverse_group_kernel(TraverseParams p)
         add_counter(p.counters, C_CH_CAND, n_cand);
         add_counter(p.counters, C_CH_SLOW, n_slow);
     }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1455,12 +1531,12 @@ __global__ __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(BLOCK) v
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = p.count ? *p.count : p.n;
-    const int s0 = blockIdx.x * (BLOCK * K);
-    if (s0 >= n) return;
     int g_per_y = (p.num_ngroups + (int)gridDim.y - 1) / (int)gridDim.y;
     g_per_y = (g_per_y + BAND_TILE_GROUPS - 1) / BAND_TILE_GROUPS * BAND_TILE_GROUPS;
     const int g_begin = blockIdx.y * g_per_y, g_end = min(g_begin + g_per_y, p.num_ngroups);
     if (g_begin >= g_end) return;
+    // a fixed number of workgroups along x: each takes every gridDim.x-th block of 256 K rays
+    for (int s0 = blockIdx.x * (BLOCK * K); s0 < n; s0 += (int)gridDim.x * (BLOCK * K)) {
 
     int slot[K];
     float ox[K], oy[K], oz[K], bx[K], by[K], bz[K];
@@ -1595,6 +1671,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(BLOCK) v
         add_counter(p.counters, C_CH_CAND, n_cand);
         add_counter(p.counters, C_CH_SLOW, n_slow);
     }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1664,13 +1741,13 @@ __global__ __launch_bounds__(BLOCK) void traverse_bandcell_kernel(TraverseParams
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = p.count ? *p.count : p.n;
-    const int R = p.rays_per_wave;
-    const int s0 = (blockIdx.x * (BLOCK / 64) + wave) * R;
-    const int s = s0 + lane;
-    if (s0 >= n) return; // the whole wavefront; no barriers below
+    const int R = p.rays_per_wave > 0 ? p.rays_per_wave : rays_per_wave_for(n);
     unsigned long long *best = best_all + wave * 64;
     float4 *ray_o = ray_o_all + wave * 64, *ray_d = ray_d_all + wave * 64;
     unsigned int *queue = queue_all + wave * GRID_QCAP;
+    const int s0 = (blockIdx.x * (BLOCK / 64) + wave) * R;
+    if (s0 >= n) return; // the whole wavefront (the launch is laid out for the longest list); no barriers below
+    const int s = s0 + lane;
 
     const bool valid = lane < R && s < n;
     const int sl = valid ? (p.alist ? p.alist[s] : s) : 0;
@@ -1803,7 +1880,7 @@ __global__ __launch_bounds__(BLOCK) void traverse_voxel_kernel(TraverseParams p)
     const int tid = threadIdx.x;
     const int n = p.count ? *p.count : p.n;
     const int s = blockIdx.x * BLOCK + tid;
-    if ((s & ~63) >= n) return; // the whole wavefront
+    if ((s & ~63) >= n) return; // the whole wavefront (the launch is laid out for the longest list)
     const bool valid = s < n;
     const int sl = valid ? (p.alist ? p.alist[s] : s) : 0;
     const float qn = __int_as_float(0x7fc00000);
@@ -1905,9 +1982,8 @@ __global__ __launch_bounds__(BLOCK) void intersect_finish_kernel(RaySoA r, const
                                                                  unsigned long long *counters)
 {
     const int n = count ? *count : n_fixed;
-    const int slot = blockIdx.x * BLOCK + threadIdx.x;
     if (blockIdx.x == 0 && threadIdx.x == 0) add_counter(counters, C_CH_RAYS, (unsigned long long)n);
-    if (slot >= n) return;
+    RT_FOR_EACH_SLOT(slot, n) {
     const int i = list ? list[slot] : slot;
     const v3 o = rtx::V(job.ox[slot], job.oy[slot], job.oz[slot]);
     const v3 d = rtx::V(job.dx[slot], job.dy[slot], job.dz[slot]);
@@ -1948,6 +2024,7 @@ __global__ __launch_bounds__(BLOCK) void intersect_finish_kernel(RaySoA r, const
         r.cx[i] = 0.0f; r.cy[i] = 0.0f; r.cz[i] = (kind == 2) ? 1.0f : 0.0f;
     }
     depth[i] = rtx::distance3(ob, rtx::V(cam.pos[0], cam.pos[1], cam.pos[2]));
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1967,23 +2044,27 @@ __global__ __launch_bounds__(BLOCK) void intersect_finish_kernel(RaySoA r, const
 __global__ __launch_bounds__(BLOCK) void color_begin_kernel(RaySoA r, const int *__restrict__ list0,
                                                             const int *__restrict__ count, Scratch s)
 {
-    const int slot = blockIdx.x * BLOCK + threadIdx.x;
-    if (slot >= *count) return;
-    const int i = list0[slot];
-    s.sox[slot] = r.ox[i]; s.soy[slot] = r.oy[i]; s.soz[slot] = r.oz[i];
-    s.lr[slot] = 0.0f; s.lg[slot] = 0.0f; s.lb[slot] = 0.0f;
-    s.lit[slot] = 0;
+    const int n = *count;
+    RT_FOR_EACH_SLOT(slot, n) {
+        const int i = list0[slot];
+        s.sox[slot] = r.ox[i]; s.soy[slot] = r.oy[i]; s.soz[slot] = r.oz[i];
+        s.lr[slot] = 0.0f; s.lg[slot] = 0.0f; s.lb[slot] = 0.0f;
+        s.lit[slot] = 0;
+    }
 }
 
 // raycol_cs.glsl:39-47
 __global__ __launch_bounds__(BLOCK) void shadow_setup_kernel(const int *__restrict__ count, Scratch s, Job job,
                                                              float lx, float ly, float lz, SharedOrigin so,
-                                                             unsigned long long *counters, unsigned int *keys)
+                                                             unsigned long long *counters, unsigned int *keys,
+                                                             int *n_out)
 {
     const int n = *count;
-    const int slot = blockIdx.x * BLOCK + threadIdx.x;
-    if (blockIdx.x == 0 && threadIdx.x == 0) add_counter(counters, C_SH_RAYS, (unsigned long long)n);
-    if (slot >= n) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        add_counter(counters, C_SH_RAYS, (unsigned long long)n);
+        if (n_out) *n_out = n; // for the kernel log
+    }
+    RT_FOR_EACH_SLOT(slot, n) {
     const v3 lpos = rtx::V(lx, ly, lz);
     v3 o = rtx::V(s.sox[slot], s.soy[slot], s.soz[slot]);
     const v3 ld = rtx::normalize(rtx::sub(lpos, o));
@@ -1998,6 +2079,7 @@ __global__ __launch_bounds__(BLOCK) void shadow_setup_kernel(const int *__restri
     prepare_shared(job, slot, o2, ld, so.origin, so.center, so.radius, so.reach_max, so.sign);
     // sorted by the cell of the direction in which the light sees them (rt_grid.h)
     if (keys) keys[slot] = rtg::oct_cell(-ld.x, -ld.y, -ld.z, so.key_bits);
+    }
 }
 
 // spheres of the shadow trace, then raycol_cs.glsl:50-79 for the rays that reach the light
@@ -2007,19 +2089,20 @@ __global__ __launch_bounds__(BLOCK) void shadow_finish_kernel(RaySoA r, const in
                                                               Job job, rt_light light, Camera cam)
 {
     const int n = acount ? *acount : n_fixed;
-    const int a = blockIdx.x * BLOCK + threadIdx.x;
-    if (a >= n) return;
+    RT_FOR_EACH_SLOT(a, n) {
     const int slot = alist ? alist[a] : a;
-    if (s.occ[slot] != 0) return;
+    if (s.occ[slot] != 0) continue;
     const v3 o2 = rtx::V(job.ox[slot], job.oy[slot], job.oz[slot]);
     const v3 ld = rtx::V(job.dx[slot], job.dy[slot], job.dz[slot]);
     const float dist = job.tmax[slot];
+    bool by_sphere = false;
 #pragma unroll
     for (int sp = 0; sp < 2; sp++) {
         float ts;
         if (rtx::ray_sphere(o2, ld, rtx::sphere_center(sp), rtx::sphere_radius(sp), ts))
-            if (ts > 0.0f && ts <= dist) return; // occluded by a sphere
+            if (ts > 0.0f && ts <= dist) by_sphere = true; // occluded by a sphere
     }
+    if (by_sphere) continue;
     const int i = list0[slot];
     const v3 o = rtx::V(s.sox[slot], s.soy[slot], s.soz[slot]);
     const v3 nn = rtx::V(r.nx[i], r.ny[i], r.nz[i]);
@@ -2038,6 +2121,7 @@ __global__ __launch_bounds__(BLOCK) void shadow_finish_kernel(RaySoA r, const in
     const v3 add = rtx::muls(rtx::muls(lcol, diffuse + kk), att);
     s.lr[slot] = s.lr[slot] + add.x; s.lg[slot] = s.lg[slot] + add.y; s.lb[slot] = s.lb[slot] + add.z;
     s.lit[slot] = 1;
+    }
 }
 
 // texture, final colour, kill rule, pixel  (raycol_cs.glsl:82-127)
@@ -2047,8 +2131,8 @@ __global__ __launch_bounds__(BLOCK) void color_finish_kernel(RaySoA r, const int
                                                              const uint32_t *__restrict__ tex, int tex_w, int tex_h,
                                                              uint32_t *__restrict__ fb)
 {
-    const int slot = blockIdx.x * BLOCK + threadIdx.x;
-    if (slot >= *count) return;
+    const int n = *count;
+    RT_FOR_EACH_SLOT(slot, n) {
     const int i = list0[slot];
     v3 fin = rtx::V(0.1f, 0.1f, 0.1f);
     if (s.lit[slot]) {
@@ -2084,6 +2168,7 @@ __global__ __launch_bounds__(BLOCK) void color_finish_kernel(RaySoA r, const int
         }
     }
     fb[i] = rtx::to_unorm8(fin.x) | (rtx::to_unorm8(fin.y) << 8) | (rtx::to_unorm8(fin.z) << 16) | 0xff000000u;
+    }
 }
 
 } // namespace rtk
