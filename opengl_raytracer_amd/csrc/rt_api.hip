@@ -102,6 +102,11 @@ struct rt_ctx {
     unsigned int *vox_off_d = nullptr;
     int *vox_entries_d = nullptr;
     int voxel_res = 0; // cells along the longest axis; 0: chosen from the number of triangles
+    // walks that traverse_voxel_kernel hands over to traverse_voxel_long_kernel: (slot, parameter), their number
+    int *walk_slot_d = nullptr;
+    float *walk_t_d = nullptr;
+    int *walk_count_d = nullptr;
+    int walk_budget = 0; // 0: chosen on the device from the number of rays
     bool camera_recs_dirty = true;
     bool light_recs_dirty = true;
     // direction cells (rt_grid.h): per shared origin (0 = camera, 1 + a = light a) the list offsets
@@ -352,6 +357,9 @@ extern "C" int rt_create(rt_ctx **out, int hip_device, int width, int height)
     CRCHK(hipMalloc(&c->row_map_d, (size_t)height * sizeof(int)));
     CRCHK(hipMalloc(&c->perm_d, c->cap * sizeof(int)));
     CRCHK(hipMalloc(&c->list, c->cap * sizeof(int)));
+    CRCHK(hipMalloc(&c->walk_slot_d, c->cap * sizeof(int)));
+    CRCHK(hipMalloc(&c->walk_t_d, c->cap * sizeof(float)));
+    CRCHK(hipMalloc(&c->walk_count_d, sizeof(int)));
     CRCHK(hipMalloc(&c->alist[0], c->cap * sizeof(int)));
     CRCHK(hipMalloc(&c->alist[1], c->cap * sizeof(int)));
     CRCHK(hipMalloc(&c->sort_keys, c->cap * sizeof(unsigned int)));
@@ -455,6 +463,9 @@ extern "C" void rt_destroy(rt_ctx *c)
     (void)hipFree(c->vox_entries_d);
     (void)hipFree(c->tex);
     (void)hipFree(c->list);
+    (void)hipFree(c->walk_slot_d);
+    (void)hipFree(c->walk_t_d);
+    (void)hipFree(c->walk_count_d);
     (void)hipFree(c->alist[0]);
     (void)hipFree(c->alist[1]);
     (void)hipFree(c->sort_keys);
@@ -669,7 +680,7 @@ extern "C" int rt_set_mesh(rt_ctx *c, const rt_vertex *vertices, int num_vertice
             rtv::build(vertices, c->num_tris, cs.rho, abs_extent, c->voxel_res, vs);
             c->vox = vs.grid;
             HIPCHK(c, hipMalloc(&c->vox_off_d, vs.off.size() * sizeof(unsigned int)));
-            HIPCHK(c, hipMalloc(&c->vox_entries_d, (vs.entries.size() + 1) * sizeof(int)));
+            HIPCHK(c, hipMalloc(&c->vox_entries_d, (vs.entries.size() + 4) * sizeof(int)));
             HIPCHK(c, hipMemcpyAsync(c->vox_off_d, vs.off.data(), vs.off.size() * sizeof(unsigned int),
                                      hipMemcpyHostToDevice, c->stream));
             if (!vs.entries.empty())
@@ -797,6 +808,10 @@ extern "C" int rt_set_option(rt_ctx *c, int option, long long value)
         if (value < 0 || value > 0xffffff00ll) break;
         c->band_list_max = (unsigned long long)value;
         c->have_mesh = false; // the lists are built by rt_set_mesh
+        return RT_OK;
+    case RT_OPT_WALK_BUDGET:
+        if (value < 0 || value > (1 << 24)) break;
+        c->walk_budget = (int)value;
         return RT_OK;
     case RT_OPT_VOXEL_RES:
         if (value < 0 || value > 128) break;
@@ -1095,9 +1110,20 @@ static int launch_traverse_clustered(rt_ctx *c, TraverseParams p, int n_upper, i
         if (int r = klog_begin(c, 1, 2, 1, false, n_slot, 0ull, 0ull, &ks)) return r;
     }
     // ---- the walk over the cells in space: well-conditioned pairs
-    hipLaunchKernelGGL(traverse_voxel_kernel, dim3(cdiv(n_upper, BLOCK)), dim3(BLOCK), 0,
-                       fork ? c->stream_side : c->stream, p);
-    HIPCHK(c, hipGetLastError());
+    {
+        hipStream_t st = fork ? c->stream_side : c->stream;
+        p.walk_slot = c->walk_slot_d;
+        p.walk_t = c->walk_t_d;
+        p.walk_count = c->walk_count_d;
+        p.walk_budget = c->walk_budget;
+        HIPCHK(c, hipMemsetAsync(c->walk_count_d, 0, sizeof(int), st));
+        hipLaunchKernelGGL(traverse_voxel_kernel, dim3(cdiv(n_upper, BLOCK)), dim3(BLOCK), 0, st, p);
+        HIPCHK(c, hipGetLastError());
+        // the long walks, one wavefront each (their number is only known on the device)
+        const int long_blocks = list_blocks(n_upper, BLOCK / 64);
+        hipLaunchKernelGGL(traverse_voxel_long_kernel, dim3(long_blocks < 2048 ? long_blocks : 2048), dim3(BLOCK), 0, st, p);
+        HIPCHK(c, hipGetLastError());
+    }
     if (fork) {
         HIPCHK(c, hipEventRecord(c->ev_join, c->stream_side));
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));

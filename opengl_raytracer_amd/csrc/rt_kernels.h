@@ -527,6 +527,11 @@ struct TraverseParams {
     rtv::Grid vox;
     const unsigned int *vox_off;
     const int *vox_entries;
+    // walks that traverse_voxel_kernel hands over to traverse_voxel_long_kernel: (slot, parameter), their number
+    int *walk_slot;
+    float *walk_t;
+    int *walk_count;
+    int walk_budget; // loop steps of a wavefront before it hands over the walks still under way (0: from the list's length)
 };
 
 // cooperative copy of one tile of the per-pair filter's 64-byte moment records into LDS; records
@@ -1871,18 +1876,34 @@ __global__ __launch_bounds__(BLOCK) void traverse_bandcell_kernel(TraverseParams
 // A walk starts from the best hit recorded so far in p.best (whoever found it: any accepted hit bounds
 // the answer).
 // Rays outside the band records' range (job.g <= 0) and rays no filter passes (job.g NaN) do not walk.
+//
+// Walks differ a lot in length -- most rays hit something after a few cells, a ray that leaves the
+// scene crosses the whole grid -- and a walk is a chain of dependent loads: a lane needs about a
+// microsecond per step, so one long walk holds its wavefront, and the launch, for hundreds of
+// microseconds.  A wavefront therefore stops after p.walk_budget steps of its loop and appends the walks
+// still under way, as (slot, parameter at which the cell they are in was entered), to a list that
+// traverse_voxel_long_kernel takes up: one WAVEFRONT per ray there, 64 cells and 64 triangles at a time.
 // grid = ray blocks of 256.
 // ---------------------------------------------------------------------------
 constexpr int VOXEL_FLUSH_MIN = 16;
+constexpr int VOXEL_BATCH = rtv::LIST_ALIGN; // triangles of a cell's list a lane takes per step of its loop
+constexpr int VOXEL_SEEN = 32; // per lane: triangles remembered as already tested (a triangle is on the lists of
+                               // all the cells around it, and a ray meets it in several of them in a row)
 
 __global__ __launch_bounds__(BLOCK) void traverse_voxel_kernel(TraverseParams p)
 {
+    constexpr int B = VOXEL_BATCH;
+    static_assert(B == 4, "a group of list entries is one int4");
+    // seen[h][lane]: the last triangle with index = h (mod VOXEL_SEEN) this lane put through the filter
+    __shared__ int seen[VOXEL_SEEN][BLOCK];
     const int tid = threadIdx.x;
     const int n = p.count ? *p.count : p.n;
     const int s = blockIdx.x * BLOCK + tid;
     if ((s & ~63) >= n) return; // the whole wavefront (the launch is laid out for the longest list)
     const bool valid = s < n;
     const int sl = valid ? (p.alist ? p.alist[s] : s) : 0;
+#pragma unroll
+    for (int h = 0; h < VOXEL_SEEN; h++) seen[h][tid] = -1;
     const float qn = __int_as_float(0x7fc00000);
     float ox = qn, oy = qn, oz = qn, dx = qn, dy = qn, dz = qn, g = qn;
     float tbest = INFINITY;
@@ -1902,14 +1923,65 @@ __global__ __launch_bounds__(BLOCK) void traverse_voxel_kernel(TraverseParams p)
     const rtv::Grid &G = p.vox;
     rtv::Walk w{};
     if (active) active = rtv::walk_start(G, ox, oy, oz, dx, dy, dz, w);
-    unsigned int idx = 0, end = 0;
+    // A walk is latency-bound -- every step depends on loads that depend on the step before -- and the
+    // launch lasts as long as its longest walk.  So a lane takes B triangles per step of its loop, and the
+    // loads are staggered so that a step waits for one round trip only:
+    //   * the walk itself stands one cell ahead of the list being read: the bounds of the next cell's list
+    //     (n_idx, n_end) are requested when the current cell is entered and have arrived when it is left;
+    //   * the indices of the NEXT batch of triangles are requested together with the records of the
+    //     current one.
+    // [idx, end) is what is left of the current cell's list after the batch in `tri`; `enter` is the
+    // parameter at which the cell of that batch was entered.
+    unsigned int idx = 0, end = 0, n_idx = 0, n_end = 0;
+    bool more = false;
+    float n_enter = 0.0f, enter = 0.0f;
+    const float inv_dn = w.inv_dn;
+    auto look_ahead = [&]() {
+        more = rtv::walk_step(G, ox, oy, oz, w);
+        n_enter = w.t_enter;
+        if (more) {
+            const int cell = rtv::cell_index(G, w);
+            n_idx = p.vox_off[cell];
+            n_end = p.vox_off[cell + 1];
+        }
+    };
+    int tri[B];
+    bool has[B];
+    // requests the next batch: the rest of the current cell's list, or the start of the next cell's
+    auto next_batch = [&]() {
+        if (active && idx >= end) {
+            if (!more) {
+                active = false;
+            } else {
+                idx = n_idx;
+                end = n_end;
+                enter = n_enter;
+                look_ahead();
+            }
+        }
+        // one aligned group of the list (padding entries are -1)
+        int4 grp = make_int4(-1, -1, -1, -1);
+        if (active && idx < end) grp = *reinterpret_cast<const int4 *>(p.vox_entries + idx);
+        tri[0] = grp.x; tri[1] = grp.y; tri[2] = grp.z; tri[3] = grp.w;
+#pragma unroll
+        for (int k = 0; k < B; k++) has[k] = tri[k] >= 0;
+        idx += B;
+    };
+#pragma unroll
+    for (int k = 0; k < B; k++) { tri[k] = -1; has[k] = false; }
     if (active) {
         const int cell = rtv::cell_index(G, w);
         idx = p.vox_off[cell];
         end = p.vox_off[cell + 1];
+        enter = w.t_enter;
+        look_ahead();
     }
+    next_batch();
     int cand = -1;
     unsigned long long n_cand = 0, n_slow = 0;
+#ifdef RT_DBG_VOXEL
+    const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime();
+#endif
 
     // the reference arithmetic on every lane's candidate
     auto flush = [&]() {
@@ -1926,45 +1998,201 @@ __global__ __launch_bounds__(BLOCK) void traverse_voxel_kernel(TraverseParams p)
         cand = -1;
     };
 
-    while (any64(active)) {
+    int steps = 0;
+    // (a small launch is all latency: it hands over sooner)
+    const int budget = p.walk_budget > 0 ? p.walk_budget : (n >= (1 << 19) ? 96 : 48);
+    while (any64(active) && steps < budget) {
+        steps++;
         n_slow++;
         if (__popcll(__builtin_amdgcn_ballot_w64(cand >= 0)) >= VOXEL_FLUSH_MIN) flush();
-        if (active && idx >= end) {
-            // the next cell, unless nothing from there on can matter
-            if (!rtv::walk_step(G, ox, oy, oz, w) || rtv::walk_done(G, w, tbest)) {
-                active = false;
-            } else {
-                const int cell = rtv::cell_index(G, w);
-                idx = p.vox_off[cell];
-                end = p.vox_off[cell + 1];
+        // nothing in the batch's cell or beyond can matter any more: the walk ends
+        if (active && rtv::walk_done_at(G, inv_dn, enter, tbest)) active = false;
+        // the records of this batch (a lane without a k-th triangle, or with one it has seen before, reads
+        // record 0: one cache line for all such lanes) ...
+        int cur[B];
+        bool cur_has[B];
+        float4 r0[B], r1[B], r2[B];
+#pragma unroll
+        for (int k = 0; k < B; k++) {
+            cur[k] = tri[k];
+            cur_has[k] = has[k] && active;
+            if (cur_has[k]) {
+                int *slot = &seen[cur[k] & (VOXEL_SEEN - 1)][tid];
+                if (*slot == cur[k]) cur_has[k] = false;
+                else *slot = cur[k];
             }
+            const float4 *rp = reinterpret_cast<const float4 *>(p.recs + (cur_has[k] ? cur[k] : 0));
+            r0[k] = rp[0]; r1[k] = rp[1]; r2[k] = rp[2];
         }
-        bool pass = false;
-        int tri = 0;
-        if (active && idx < end) {
-            tri = p.vox_entries[idx++];
+        // ... and, in the same round trip, the indices of the next
+        next_batch();
+        bool pass[B];
+#pragma unroll
+        for (int k = 0; k < B; k++) {
+            const float rec[12] = {r0[k].x, r0[k].y, r0[k].z, r0[k].w, r1[k].x, r1[k].y, r1[k].z, r1[k].w,
+                                   r2[k].x, r2[k].y, r2[k].z, r2[k].w};
             // (the triangle that holds the best hit, or is about to be tested, shows up again in the cells next to it)
-            if ((tri != idbest || !(tbest < INFINITY)) && tri != cand) {
-                const float4 *rp = reinterpret_cast<const float4 *>(p.recs + tri);
-                const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
-                const float rec[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
-                pass = rtf::filter_general(rec, ox, oy, oz, hx, hy, hz) >= -1.0f;
-            }
+            pass[k] = cur_has[k] && (cur[k] != idbest || !(tbest < INFINITY)) && cur[k] != cand &&
+                      rtf::filter_general(rec, ox, oy, oz, hx, hy, hz) >= -1.0f;
         }
-        if (any64(pass && cand >= 0)) flush(); // a lane needs its slot
-        if (pass) cand = tri;
+#pragma unroll
+        for (int k = 0; k < B; k++) {
+            if (any64(pass[k] && cand >= 0)) flush(); // a lane needs its slot
+            if (pass[k] && cur[k] != cand) cand = cur[k];
+        }
     }
     flush();
+
+    // out of budget: the walks still under way go on the list, from the cell of the batch that was next
+    {
+        const unsigned long long left = __builtin_amdgcn_ballot_w64(active);
+        if (left) {
+            int base = 0;
+            if ((tid & 63) == 0) base = atomicAdd(p.walk_count, __popcll(left));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (active) {
+                const int pos = base + lanes_below(left);
+                p.walk_slot[pos] = sl;
+                p.walk_t[pos] = enter;
+            }
+        }
+    }
 
     if ((tid & 63) == 0) {
         add_counter(p.counters, C_CH_CAND, n_cand);
         add_counter(p.counters, C_CH_SLOW, n_slow);
         add_counter(p.counters, C_CH_PAIRS, (unsigned long long)min(64, n - (s & ~63)) * (unsigned long long)p.num_tris);
+#ifdef RT_DBG_VOXEL
+        atomicMax(p.counters + 5, n_slow);
+        atomicMax(p.counters + 7, (unsigned long long)(__builtin_amdgcn_s_memtime() - dbg_t0));
+        atomicAdd(p.counters + 8 + 3, n_slow);
+        atomicAdd(p.counters + 8 + 5, 1ull);
+#endif
     }
     if (valid && (tbest < tfirst || (tbest == tfirst && idbest < idfirst))) {
         const unsigned long long key =
             ((unsigned long long)__float_as_uint(tbest) << 32) | (unsigned long long)(unsigned int)idbest;
         atomicMin(&p.best[sl], key);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// The long walks traverse_voxel_kernel hands over: one wavefront per ray.  Every lane steps the same
+// walk (rt_voxel.h) 64 cells ahead and lane k keeps cell k; the 64 list bounds arrive in one round trip;
+// the lists, laid end to end, are then taken 64 triangles at a time, one per lane -- index, record,
+// general edge filter, and for the few that pass the reference arithmetic on the spot.  The
+// wavefront's best (t, index) is the minimum over its lanes; the stopping rule of rtv::walk_done is
+// applied per cell, with the best known when the cell's batch starts.  The best hit so far comes from
+// p.best (the per-lane kernel wrote what it had found) and goes back there.
+// grid = any number of workgroups of four independent wavefronts, each taking every W-th ray.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void traverse_voxel_long_kernel(TraverseParams p)
+{
+    __shared__ int s_first_all[BLOCK / 64][65];           // position of each cell's list in the concatenation
+    __shared__ unsigned int s_start_all[BLOCK / 64][64];  // where each list starts in vox_entries
+    __shared__ float s_enter_all[BLOCK / 64][64];         // parameter at which each cell is entered
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int *s_first = s_first_all[wave];
+    unsigned int *s_start = s_start_all[wave];
+    float *s_enter = s_enter_all[wave];
+    const int n = *p.walk_count;
+    const rtv::Grid &G = p.vox;
+    const int n_waves = (int)gridDim.x * (BLOCK / 64);
+    unsigned long long n_cand = 0, n_slow = 0;
+    for (int r = blockIdx.x * (BLOCK / 64) + wave; r < n; r += n_waves) {
+        const int sl = p.walk_slot[r];
+        const float t_from = p.walk_t[r];
+        const float ox = p.job.ox[sl], oy = p.job.oy[sl], oz = p.job.oz[sl];
+        const float dx = p.job.dx[sl], dy = p.job.dy[sl], dz = p.job.dz[sl];
+        const float g = p.job.g[sl];
+        const float hx = dx * g, hy = dy * g, hz = dz * g;
+        unsigned long long best = p.best[sl]; // (t bits, index): the same for every lane
+        const unsigned long long first_best = best;
+        rtv::Walk w{};
+        bool alive = rtv::walk_start(G, ox, oy, oz, dx, dy, dz, w, t_from);
+        bool walk_over = false;
+        while (alive) {
+            // the next 64 cells of the walk: lane k keeps the k-th
+            int my_cell = -1;
+            float my_enter = INFINITY;
+            for (int k = 0; k < 64; k++) {
+                if (lane == k) {
+                    my_cell = rtv::cell_index(G, w);
+                    my_enter = w.t_enter;
+                }
+                if (!rtv::walk_step(G, ox, oy, oz, w)) {
+                    walk_over = true;
+                    break;
+                }
+            }
+            unsigned int start = 0;
+            int cnt = 0;
+            if (my_cell >= 0) {
+                start = p.vox_off[my_cell];
+                cnt = (int)(p.vox_off[my_cell + 1] - start);
+            }
+            // exclusive prefix sum of the list lengths over the lanes
+            int incl = cnt;
+#pragma unroll
+            for (int sh = 1; sh < 64; sh <<= 1) {
+                const int up = __shfl_up(incl, sh, 64);
+                if (lane >= sh) incl += up;
+            }
+            const int total = __builtin_amdgcn_readlane(incl, 63);
+            s_first[lane] = incl - cnt;
+            if (lane == 63) s_first[64] = total;
+            s_start[lane] = start;
+            s_enter[lane] = my_enter;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // the other lanes read these
+            __builtin_amdgcn_wave_barrier();
+            for (int base = 0; base < total && alive; base += 64) {
+                n_slow++;
+                const int e = base + lane;
+                const bool has = e < total;
+                // the cell whose list holds entry e: the last k with s_first[k] <= e
+                int c = 0;
+#pragma unroll
+                for (int sh = 32; sh > 0; sh >>= 1)
+                    if (s_first[c + sh] <= e) c += sh;
+                const float tb = __uint_as_float((unsigned int)(best >> 32));
+                // the batch starts in cell c of lane 0: nothing from there on can matter -> the walk ends
+                const int c0 = __builtin_amdgcn_readfirstlane(c);
+                if (rtv::walk_done_at(G, w.inv_dn, s_enter[c0], tb)) {
+                    alive = false;
+                    break;
+                }
+                unsigned long long mine = ~0ull;
+                if (has && !rtv::walk_done_at(G, w.inv_dn, s_enter[c], tb)) {
+                    const int tri = p.vox_entries[s_start[c] + (unsigned int)(e - s_first[c])]; // -1: padding
+                    const float4 *rp = reinterpret_cast<const float4 *>(p.recs + (tri < 0 ? 0 : tri));
+                    const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
+                    const float rec[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
+                    if (tri >= 0 && rtf::filter_general(rec, ox, oy, oz, hx, hy, hz) >= -1.0f) {
+                        n_cand++;
+                        const v3 X = vpos(p.verts, 3 * tri), Y = vpos(p.verts, 3 * tri + 1), Z = vpos(p.verts, 3 * tri + 2);
+                        float t;
+                        if (rtx::ray_vs_triangle(rtx::V(ox, oy, oz), rtx::V(dx, dy, dz), X, Y, Z, t) && t > 0.0f)
+                            mine = ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)(unsigned int)tri;
+                    }
+                }
+                if (any64(mine != ~0ull)) {
+                    // minimum of (t bits, index) over the lanes: smallest t, lowest index among equal t
+#pragma unroll
+                    for (int sh = 32; sh > 0; sh >>= 1) {
+                        const unsigned long long other = __shfl_xor(mine, sh, 64);
+                        mine = other < mine ? other : mine;
+                    }
+                    if (mine < best) best = mine;
+                }
+            }
+            __builtin_amdgcn_wave_barrier(); // the tables are rewritten by the next round
+            if (alive && (walk_over || rtv::walk_done(G, w, __uint_as_float((unsigned int)(best >> 32))))) alive = false;
+        }
+        if (lane == 0 && best < first_best) atomicMin(&p.best[sl], best);
+    }
+    if (lane == 0) {
+        add_counter(p.counters, C_CH_CAND, n_cand);
+        add_counter(p.counters, C_CH_SLOW, n_slow);
     }
 }
 

@@ -61,6 +61,7 @@ struct Grid {         // (named members, not arrays: an axis chosen per lane mus
 };
 
 constexpr float STOP_FACTOR = 0.94f;
+constexpr int LIST_ALIGN = 4; // entries of a cell's list come in groups of this many (padded with -1)
 
 RT_HD float plane_at(const Grid &G, float gmin, int i) { return fmaf((float)i, G.cs, gmin); }
 
@@ -98,10 +99,12 @@ RT_HD int start_index(float p, float gmin, float inv_cs, int n)
     return (int)q;
 }
 
-// Places the walk in the cell where the line enters the grid (or rho_max + margin behind the ray's
-// origin, whichever comes later).  false: the line misses the grid, or the ray is not one the walk
-// handles (zero or non-finite direction).
-RT_HD bool walk_start(const Grid &G, float ox, float oy, float oz, float dx, float dy, float dz, Walk &w)
+// Places the walk in the cell where the line enters the grid, or rho_max + margin behind the ray's
+// origin, or at parameter t_from (a walk taken up again: the parameter at which it had entered the
+// cell it was in; -inf for a new walk), whichever comes last.  false: the line misses the grid, or
+// the ray is not one the walk handles (zero or non-finite direction).
+RT_HD bool walk_start(const Grid &G, float ox, float oy, float oz, float dx, float dy, float dz, Walk &w,
+                      float t_from = -INFINITY)
 {
     const float dn = sqrtf(dx * dx + dy * dy + dz * dz);
     if (!(dn > 0.0f) || !(dn < INFINITY)) return false;
@@ -109,7 +112,7 @@ RT_HD bool walk_start(const Grid &G, float ox, float oy, float oz, float dx, flo
     const float lim = dn * G.flat;
     const bool fx = !(fabsf(dx) > lim), fy = !(fabsf(dy) > lim), fz = !(fabsf(dz) > lim);
     w.invx = 1.0f / dx; w.invy = 1.0f / dy; w.invz = 1.0f / dz;
-    float t0 = -G.back * w.inv_dn, t1 = INFINITY;
+    float t0 = fmaxf(-G.back * w.inv_dn, t_from), t1 = INFINITY;
     if (!clip_axis(ox, dx, w.invx, fx, G.gminx, G.gmaxx, t0, t1)) return false;
     if (!clip_axis(oy, dy, w.invy, fy, G.gminy, G.gmaxy, t0, t1)) return false;
     if (!clip_axis(oz, dz, w.invz, fz, G.gminz, G.gmaxz, t0, t1)) return false;
@@ -152,19 +155,20 @@ RT_HD bool walk_step(const Grid &G, float ox, float oy, float oz, Walk &w)
     return i >= 0 && i < nn;
 }
 
-// true: no cell from the current one on can hold a hit whose computed t^ is <= tbest
-RT_HD bool walk_done(const Grid &G, const Walk &w, float tbest)
+// true: no cell entered at parameter t_enter or later can hold a hit whose computed t^ is <= tbest
+RT_HD bool walk_done_at(const Grid &G, float inv_dn, float t_enter, float tbest)
 {
-    return fmaf(STOP_FACTOR, w.t_enter, -(G.slack * w.inv_dn)) > tbest;
+    return fmaf(STOP_FACTOR, t_enter, -(G.slack * inv_dn)) > tbest;
 }
+RT_HD bool walk_done(const Grid &G, const Walk &w, float tbest) { return walk_done_at(G, w.inv_dn, w.t_enter, tbest); }
 
 // ---------------------------------------------------------------------------------------------
 // Host-side build.
 // ---------------------------------------------------------------------------------------------
 struct VoxelSet {
     Grid grid{};
-    std::vector<uint32_t> off;     // cells + 1
-    std::vector<int32_t> entries;  // triangle indices, cell after cell
+    std::vector<uint32_t> off;     // cells + 1; every list starts on a multiple of LIST_ALIGN entries
+    std::vector<int32_t> entries;  // triangle indices, cell after cell, each list padded with -1
     double rho_max = 0.0;
     double margin = 0.0;
 };
@@ -305,9 +309,11 @@ inline void build(const rt_vertex *v, int num_tris, const std::vector<double> &r
                     cnt[cell + 1]++;
                 }
     }
-    for (size_t i = 0; i < ncell; i++) cnt[i + 1] += cnt[i];
+    // lists are padded to whole groups of LIST_ALIGN entries: a lane reads a group with one 16-byte load
+    for (size_t i = 0; i < ncell; i++)
+        cnt[i + 1] = cnt[i] + (cnt[i + 1] + (uint32_t)LIST_ALIGN - 1) / (uint32_t)LIST_ALIGN * (uint32_t)LIST_ALIGN;
     out.off = cnt;
-    out.entries.assign(cells.size(), 0);
+    out.entries.assign(cnt[ncell], -1);
     std::vector<uint32_t> cur(cnt.begin(), cnt.end() - 1);
     for (size_t i = 0; i < cells.size(); i++) out.entries[cur[cells[i]]++] = tris[i];
 }

@@ -209,6 +209,7 @@ extern "C" void fm_check_clustered(int n_tris, const float *verts, int n_rays, c
                         const int cell = rtv::cell_index(G, w);
                         for (uint32_t e = vs.off[cell]; e < vs.off[cell + 1]; e++) {
                             const int t = vs.entries[e];
+                            if (t < 0) continue; // padding
                             if (!visited[t]) { visited[t] = 1; touched.push_back(t); }
                         }
                     } while (rtv::walk_step(G, o[0], o[1], o[2], w));
@@ -265,6 +266,7 @@ extern "C" void fm_check_clustered(int n_tris, const float *verts, int n_rays, c
                         const int cell = rtv::cell_index(G, w);
                         for (uint32_t e = vs.off[cell]; e < vs.off[cell + 1]; e++) {
                             const int k = vs.entries[e];
+                            if (k < 0) continue; // padding
                             tests_n++;
                             if (!(rtf::filter_general(grec[k].v, o[0], o[1], o[2], d[0] * gg, d[1] * gg, d[2] * gg) >= -1.0f))
                                 continue;
