@@ -3,25 +3,30 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
 
-A step is one whole frame per GPU (or one batch of views): raygen, then P x {intersect, color},
-with the scene already resident in HBM, plus -- for N > 1 -- the gather of the RGBA8 frames
-to rank 0 over RCCL.  One process per GPU (torch.distributed, backend nccl), scene replicated, no
-collective on the data path.  Two ways to shard (--sharding):
-  batch  (default) every rank renders one whole frame of the workload per step, N frames per step:
-         the work per GPU is fixed ("weak");
-  tiles  ONE frame is cut into interleaved row tiles over the ranks: the total work is fixed ("strong").
-The 64-view workload deals its fixed set of views over the ranks ("strong").
+A step is one whole frame (or one batch of views): raygen, then P x {intersect, color}, with the
+scene already resident in HBM, plus -- for N > 1 -- the gather of the RGBA8 pixels to rank 0 over
+RCCL.  One process per GPU (torch.distributed, backend nccl), scene replicated, no collective on the
+data path.  With --gpus N > 1 and no launcher around it (no WORLD_SIZE in the environment) this
+program starts the N ranks itself, as fresh processes, before anything here touches a GPU, and
+relays rank 0's line.
 
-value = rays actually traced (closest-hit rays entering traversal + shadow rays traced,
-summed over passes and ranks) per second of wall time, in Mrays/s.  Rays that missed
-everything are dead (the reference skips them in intersect; in color they provably shade
-to the background grey, so no shadow ray is traced for them and none is counted).
+Two ways to shard (--sharding):
+  tiles  ONE frame is cut into interleaved row tiles over the ranks: the total work is fixed
+         ("strong") -- the default for the single-frame workloads;
+  batch  every rank renders whole frames: the 64-view workload deals its fixed set of views over the
+         ranks ("strong", its default); a single-frame workload renders one frame per rank ("weak").
+
+value = rays actually traced (closest-hit rays entering traversal + shadow rays traced, summed over
+passes and ranks) per second of wall time, in Mrays/s.  Rays that missed everything are dead (the
+reference skips them in intersect; in color they provably shade to the background grey, so no
+shadow ray is traced for them and none is counted).
 
 Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -31,10 +36,28 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FLOP_PER_TEST = 52.0          # Moller-Trumbore as the reference writes it (trace.glsl:5-20)
-PEAK_FP32_TFLOPS = 157.3      # MI355X vector FP32 peak
+PEAK_FP32_TFLOPS = 157.3      # MI355X vector FP32 peak: 256 CUs x 64 lanes x 4 FLOP (packed FMA) x 2.4 GHz
 PEAK_HBM_GBS = 8000.0         # MI355X HBM3E
+NOMINAL_CLOCK_HZ = 2.4e9
+# VALU issue peak: a SIMD is 16 lanes wide, so a wave64 instruction holds it for 4 clocks (the counters
+# agree: SQ_ACTIVE_INST_VALU, in quad-cycles, is 1.0 per SQ_INSTS_VALU in these kernels):
+# 256 CUs x 4 SIMDs x 0.25 wave-instructions per clock x 2.4 GHz = 614.4 G/s.  One FLOP per lane per
+# instruction -- all this arithmetic may use, since fusing a multiply into an add changes the bits -- is
+# then 39.3 TFLOP/s, a quarter of the packed-FMA peak.
+PEAK_VALU_GINST = 256 * 4 * 0.25 * NOMINAL_CLOCK_HZ / 1e9
+PEAK_UNFUSED_TFLOPS = PEAK_VALU_GINST * 64 / 1e3
 RAY_PLANE_BYTES = 56.0        # raygen writes 14 float planes per ray
 METRIC = "Mrays/s (primary+secondary) at 4K vs triangle count; % FP32 VALU peak"
+
+# rocprof names of the traversal kernels, by (stage, form) of the library's kernel log
+KERNEL_NAMES = {
+    (1, 3): "rtk::traverse_grid_kernel<false>",
+    (2, 3): "rtk::traverse_grid_kernel<true>",
+    (1, 2): "rtk::traverse_bandcell_kernel",
+    (1, 4): "rtk::traverse_voxel_kernel",
+    (1, 5): "rtk::traverse_voxel_long_kernel",
+}
+SIDE_BY_SIDE = "bounce pass: rtk::traverse_bandcell_kernel beside rtk::traverse_voxel_kernel + rtk::traverse_voxel_long_kernel"
 
 
 def asset_mesh(sub, name):
@@ -125,27 +148,42 @@ def cpu_baseline(wl, seconds_hint=15.0):
                       f"{wl['passes']} passes, oracle with {threads} OpenMP threads, {dt:.1f} s"}
 
 
-def measured_traffic(workload_name, kernel_names):
-    measured_traffic.valu_issue = None
-    """HBM bytes per launch of the named kernels from the committed PMC summary (a separate rocprofv3
-    run of this command: counters cannot be read from inside the benchmark), or None."""
+def committed_counters(workload_name):
+    """Per-launch hardware counters of the kernels from the committed PMC summary (separate rocprofv3
+    runs of this program with --sweeps-in-turn: counters cannot be read from inside the benchmark)."""
     try:
         rec = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic_per_launch.json")))
         if rec.get("workload") != workload_name:
-            return None, None
-        measured_traffic.valu_issue = {k: rec["kernels"][k].get("valu_issue_frac") for k in kernel_names}
-        return (sum(float(rec["kernels"][k]["hbm_bytes_per_launch"]) for k in kernel_names),
-                "profiles/" + rec["source"] + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of this command)")
+            return {}, None
+        return rec["kernels"], "profiles/" + rec["source"]
     except (OSError, KeyError, ValueError):
-        return None, None
+        return {}, None
 
 
-def per_pair_roofline(g, job, wl, restore_mode):
-    """The brute-force loop proper, measured live: one frame in the per-pair mode (every (ray, triangle)
-    pair goes through a per-pair filter, no group rejection, no lists).  The entry is the closest-hit
-    kernel of the bounce passes (arbitrary rays, general filter): 52 algorithmic FLOP per pair against
-    the FP32 vector peak, durations from hipEvent pairs around each launch."""
-    g.set_trace_mode(0)
+def named_launches(log, in_turn):
+    """The kernel log as (rocprof kernel name, record) pairs.  A bounce pass is one record per kernel when
+    its kernels run in turn, one record for all three when they run side by side on two streams."""
+    out = []
+    for r in log:
+        stage, form = int(r["stage"]), int(r["form"])
+        if form == 2 and not in_turn:
+            name = SIDE_BY_SIDE
+        elif (stage, form) in KERNEL_NAMES:
+            name = KERNEL_NAMES[(stage, form)]
+        else:
+            name = "rtk::traverse_kernel<%d, %d, %s, %s>" % (int(r["rays_per_lane"]), form, "false" if stage == 1 else "true",
+                                                          "true" if int(r["exact"]) else "false")
+        out.append((name, r))
+    return out
+
+
+def kernel_rooflines(g, job, wl, workload_name):
+    """One more frame after the timed region with the two kernels of a bounce pass one after the other
+    (each launch then has a duration of its own, from the hipEvent pair around it on the library's
+    stream), grouped by kernel.  For each: the executed VALU issue fraction -- wave-instructions per
+    launch (committed PMC summary) / live duration / issue peak -- which cannot exceed 1."""
+    counters, source = committed_counters(workload_name)
+    g.set_option("sweeps_in_turn", 1)
     try:
         job.render(wl["passes"])
         g.sync()
@@ -154,24 +192,79 @@ def per_pair_roofline(g, job, wl, restore_mode):
         g.sync()
         log = g.kernel_log()
     finally:
-        g.set_trace_mode(restore_mode)
+        g.set_option("sweeps_in_turn", 0)
         g.counters()
         g.stage_ms()
+    groups = {}
+    for name, r in named_launches(log, True):
+        a = groups.setdefault(name, dict(ms=0.0, launches=0, pairs=0.0, rays=0.0))
+        a["ms"] += float(r["ms"]); a["launches"] += 1; a["pairs"] += float(r["pairs"]); a["rays"] += float(r["rays"])
     out = []
-    for form, label in ((0, "bounce passes, general filter"), (1, "primary pass, shared-origin filter")):
-        sel = [r for r in log if int(r["stage"]) == 1 and int(r["form"]) == form and float(r["ms"]) > 0]
+    for name, a in sorted(groups.items(), key=lambda kv: -kv[1]["ms"]):
+        avg_ms = a["ms"] / a["launches"]
+        pmc = counters.get(name)
+        entry = {"bound": "valu", "kernel": name, "launches": a["launches"], "avg_launch_ms": avg_ms,
+                 "total_ms_per_frame": a["ms"], "rays_per_launch": a["rays"] / a["launches"],
+                 "achieved": None, "peak": PEAK_VALU_GINST, "unit": "G VALU wave-instructions/s", "frac": None,
+                 "traffic": None, "traffic_unit": "bytes of HBM per launch"}
+        if pmc and pmc.get("valu_wave_insts_per_launch"):
+            ginst = float(pmc["valu_wave_insts_per_launch"]) / (avg_ms * 1e-3) / 1e9
+            entry.update(achieved=ginst, frac=ginst / PEAK_VALU_GINST, traffic=pmc.get("hbm_bytes_per_launch"),
+                         counters_source=source)
+        out.append(entry)
+    return out
+
+
+def exact_mode_roofline(g, job, wl):
+    """The reference's loop as written, measured in EXECUTED FLOPs: the all-pairs mode (52 FLOP on every
+    (ray, triangle) pair, vertices streamed through LDS tiles) on every 32nd row tile of the frame, two
+    passes; its closest-hit launches against the FP32 vector peak."""
+    g.set_trace_mode(1)
+    try:
+        g.set_row_tiles(8, 0, 32)
+        g.render(1); g.sync(); g.kernel_log()
+        g.render(2); g.sync()
+        log = g.kernel_log()
+    finally:
+        g.set_trace_mode(2)
+        g.set_row_tiles(job.tile_rows, 0, 1)
+        g.counters(); g.stage_ms()
+    out = []
+    for form, label in ((0, "bounce pass (arbitrary rays)"), (1, "primary pass (rays from the camera)")):
+        sel = [r for r in log if int(r["stage"]) == 1 and int(r["form"]) == form and int(r["exact"]) == 1 and float(r["ms"]) > 0]
         if not sel:
             continue
         ms = sum(float(r["ms"]) for r in sel)
         pairs = sum(float(r["pairs"]) for r in sel)
         tf = pairs * FLOP_PER_TEST / (ms * 1e-3) / 1e12
-        out.append({"bound": "valu", "kernel": f"traverse_kernel<K={int(sel[0]['rays_per_lane'])},"
-                                                f"{'general' if form == 0 else 'shared-origin'},closest> ({label})",
-                    "trace_mode": "filtered", "achieved": tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                    "frac": tf / PEAK_FP32_TFLOPS, "traffic": None, "launches": len(sel),
-                    "avg_launch_ms": ms / len(sel), "pairs_per_launch": pairs / len(sel),
-                    "flop_per_pair": FLOP_PER_TEST})
+        out.append({"bound": "valu", "kernel": "rtk::traverse_kernel<%d, %d, false, true> (%s)" % (int(sel[0]["rays_per_lane"]), form, label),
+                    "trace_mode": "exact", "achieved": tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s (executed: 52 per pair)",
+                    "frac": tf / PEAK_FP32_TFLOPS, "frac_of_unfused_peak": tf / PEAK_UNFUSED_TFLOPS, "unfused_peak": PEAK_UNFUSED_TFLOPS,
+                    "traffic": None,
+                    "launches": len(sel), "avg_launch_ms": ms / len(sel), "pairs_per_launch": pairs / len(sel),
+                    "sample": "row tiles of 8 rows, every 32nd, of the same frame"})
     return out
+
+
+def spawn_ranks(args):
+    """--gpus N without a launcher: N fresh processes of this program, one per GPU, started before this
+    process has touched a GPU; rank 0's output is relayed."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [p.wait() for p in procs]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return max(abs(c) for c in codes)
 
 
 def main():
@@ -181,73 +274,107 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="soup64k_4k_p6")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-per-pair", action="store_true", help="skip the per-pair-mode roofline frame (N = 1)")
+    ap.add_argument("--no-kernel-rooflines", action="store_true",
+                    help="skip the frames after the timed region that measure the kernels one by one (N = 1)")
     ap.add_argument("--trace-mode", type=int, default=2, help="0 filtered, 1 exact, 2 clustered (default)")
-    ap.add_argument("--sharding", choices=("batch", "tiles"), default="batch",
-                    help="N > 1: one whole frame per rank per step (default), or one frame in row tiles")
+    ap.add_argument("--sweeps-in-turn", action="store_true",
+                    help="the two kernels of a bounce pass one after the other in the timed region too (for profiles)")
+    ap.add_argument("--sharding", choices=("auto", "batch", "tiles"), default="auto",
+                    help="N > 1: one frame in row tiles (default for single-frame workloads), or whole frames per rank")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the gather (nccl = RCCL)")
+    ap.add_argument("--renderer", choices=("hip", "oracle"), default="hip",
+                    help="oracle: the CPU restatement stands in for the GPU (tests of this program's launcher only)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
 
     import torch
     import torch.distributed as dist
-    import opengl_raytracer_amd as rt
     from opengl_raytracer_amd import sharding
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    on_gpu = args.renderer == "hip"
+    if on_gpu:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank) if on_gpu else torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
+        if on_gpu and args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
     if args.gpus != world and rank == 0:
         print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
-    dev = torch.device("cuda", local_rank)
 
     wl = workload(args.workload)
-    g = rt.RayTracer(wl["width"], wl["height"], device=local_rank)
+    if on_gpu:
+        import opengl_raytracer_amd as rt
+        g = rt.RayTracer(wl["width"], wl["height"], device=local_rank)
+        g.set_trace_mode(args.trace_mode)
+        if args.sweeps_in_turn:
+            g.set_option("sweeps_in_turn", 1)
+    else:
+        from oracle.rt_oracle import Oracle
+        g = Oracle(wl["width"], wl["height"], threads=max(1, (os.cpu_count() or 2) // max(world, 1)))
     setup_scene(g, wl)
-    g.set_trace_mode(args.trace_mode)
+    mode = args.sharding
+    if mode == "auto":
+        mode = "tiles" if wl["kind"] == "tiles" else "batch"
     scaling = "strong"
-    if wl["kind"] == "tiles" and (world == 1 or args.sharding == "tiles"):
-        job = sharding.TileShardedFrame(g, wl["width"], wl["height"], dev)
+    if wl["kind"] == "tiles" and (world == 1 or mode == "tiles"):
+        job = sharding.TileShardedFrame(g, wl["width"], wl["height"], dev, bind_device_framebuffer=on_gpu)
         shard_desc = f"image tiles of {job.tile_rows} rows, interleaved over {world} rank(s), gathered to rank 0"
-        if world == 1:
-            scaling = "weak"  # one rank, one frame: the N = 1 point of the frame-batch series
     elif wl["kind"] == "tiles":
         # one whole frame of the workload per rank per step
-        job = sharding.FrameBatch(g, wl["width"], wl["height"], wl["cams"] * world, dev)
+        job = sharding.FrameBatch(g, wl["width"], wl["height"], wl["cams"] * world, dev, bind_device_framebuffer=on_gpu)
         shard_desc = f"frame batch: {world} frames per step, one per rank, gathered to rank 0"
         scaling = "weak"
     else:
-        job = sharding.FrameBatch(g, wl["width"], wl["height"], wl["cams"], dev)
+        job = sharding.FrameBatch(g, wl["width"], wl["height"], wl["cams"], dev, bind_device_framebuffer=on_gpu)
         shard_desc = f"frame batch: view k on rank k % {world}, frames gathered to rank 0"
 
     def sync_all():
-        g.sync()
-        torch.cuda.synchronize(dev)
+        if on_gpu:
+            g.sync()
+            torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
-            torch.cuda.synchronize(dev)
+            if on_gpu:
+                torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
         job.render(wl["passes"])
     sync_all()
-    g.counters()
-    g.kernel_log()
-    g.stage_ms()
+    if on_gpu:
+        g.counters()
+        g.kernel_log()
+        g.stage_ms()
 
+    frame = None
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        job.render(wl["passes"])
+        frame = job.render(wl["passes"])
     sync_all()
     dt = time.perf_counter() - t0
+    # checksum of the gathered pixels of the last step (the same for every N and either renderer)
+    frame_crc = None
+    if rank == 0 and frame is not None and not (world > 1 and scaling == "weak"):
+        import zlib
+        frame_crc = "%08x" % zlib.crc32(frame.contiguous().cpu().numpy().tobytes())
 
-    cnt = g.counters()
-    log = g.kernel_log()
-    stage_ms = g.stage_ms()
+    if on_gpu:
+        cnt = g.counters()
+        log = g.kernel_log()
+        stage_ms = g.stage_ms()
+    else:
+        # the stand-in renderer counts nothing: rays = pixels rendered
+        n_px = float(getattr(g, "num_rays", wl["width"] * wl["height"])) * len(getattr(job, "mine", [0])) * args.steps
+        cnt = dict(closest_rays=n_px, shadow_rays=0, closest_pairs=0, shadow_pairs=0, closest_candidates=0,
+                   shadow_candidates=0, closest_slow_steps=0, shadow_slow_steps=0)
+        log, stage_ms = [], [0.0, 0.0, 0.0]
     tot = torch.tensor([cnt["closest_rays"], cnt["shadow_rays"], cnt["closest_pairs"], cnt["shadow_pairs"],
                         cnt["closest_candidates"], cnt["shadow_candidates"], cnt["closest_slow_steps"],
                         cnt["shadow_slow_steps"]], dtype=torch.float64, device=dev)
@@ -261,61 +388,23 @@ def main():
     if rank == 0:
         steps = max(args.steps, 1)
         rays = tot[0] + tot[1]
-        # dominant kernel on rank 0: group the launch log by kernel variant
+        # traversal launches of the timed region on rank 0, by kernel (a side-by-side bounce pass is one
+        # record for its two kernels)
         groups = {}
-        for r in log:
-            key = (int(r["stage"]), int(r["form"]), int(r["rays_per_lane"]), int(r["exact"]))
-            if key[1] == 2:
-                # the clustered closest-hit traversal covers a pass's pairs with one launch (both sweeps)
-                # or with two (band sweep over direction-sorted rays, logged with the pairs; sphere sweep,
-                # logged with 0 pairs): one entry, one "launch" per pass, durations added
-                key = (key[0], 2, 0, key[3])
-            a = groups.setdefault(key, dict(ms=0.0, launches=0, pairs=0.0))
-            a["ms"] += float(r["ms"]); a["pairs"] += float(r["pairs"])
-            a["launches"] += 1 if (key[1] != 2 or float(r["pairs"]) > 0) else 0
-        kernels = []
-        for (stage, form, k, exact), a in sorted(groups.items(), key=lambda kv: -kv[1]["ms"]):
-            pairs = a["pairs"]
-            if stage == 2:  # shadow traversal: pairs actually executed (early exit), from the counters
-                share = a["pairs"] / max(sum(x["pairs"] for kk, x in groups.items() if kk[0] == 2), 1.0)
-                pairs = cnt["shadow_pairs"] * share
-            name = ("closest_hit_kernel" if stage == 1 else "shade_kernel") + \
-                   f"<K={k},{('general', 'shared-origin', 'clustered', 'shared-origin direction cells')[form]}{',exact' if exact else ''}>"
-            if form == 2:
-                name = "closest_hit_kernel<clustered: band sweep (traverse_bandcell_kernel) + sphere sweep (traverse_cluster_kernel) per pass>"
-            a["launches"] = max(a["launches"], 1)
-            kernels.append(dict(kernel=name, launches=a["launches"], avg_ms=a["ms"] / a["launches"],
-                                total_ms=a["ms"], pairs_per_launch=pairs / a["launches"],
-                                tflops=pairs * FLOP_PER_TEST / (a["ms"] * 1e-3) / 1e12 if a["ms"] > 0 else 0.0))
-        dom = kernels[0] if kernels else None
-        roofline = None
-        if dom:
-            names = {"clustered": ["rtk::traverse_bandcell_kernel", "rtk::traverse_cluster_kernel<1, 2>"],
-                     "shade_kernel<K=1,shared-origin direction cells>": ["rtk::traverse_grid_kernel<true>"],
-                     "closest_hit_kernel<K=1,shared-origin direction cells>": ["rtk::traverse_grid_kernel<false>"]}
-            traffic, traffic_src = measured_traffic(
-                args.workload if args.trace_mode == 2 and world == 1 else None,
-                names["clustered"] if "clustered:" in dom["kernel"] else names.get(dom["kernel"], ["?"]))
-            roofline = {"bound": "valu", "kernel": dom["kernel"], "achieved": dom["tflops"],
-                        "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": dom["tflops"] / PEAK_FP32_TFLOPS,
-                        "traffic": traffic, "traffic_unit": "bytes of HBM per launch", "traffic_source": traffic_src,
-                        # executed VALU wave-instructions / (1024 SIMDs x 0.5 per clock x measured clock), same source
-                        "executed_valu_issue_frac": measured_traffic.valu_issue,
-                        "avg_launch_ms": dom["avg_ms"], "launches": dom["launches"],
-                        "flop_per_pair": FLOP_PER_TEST, "pairs_per_launch": dom["pairs_per_launch"],
-                        "note": "FP32 vector ALU bound (no MFMA). achieved = 52 FLOP (the reference's test as "
-                                "written) x (ray,triangle) pairs decided per launch / launch duration from "
-                                "hipEvent pairs around each launch on the library's stream (a clustered bounce pass: "
-                                "from the fork of its two side-by-side kernels to their join). Pairs are mostly "
-                                "decided by conservative group tests instead of the 52 FLOPs, so frac exceeds 1; "
-                                "the executed VALU issue rate per kernel is in profiles/*rocprof_summary*.txt"}
+        for name, r in named_launches(log, args.sweeps_in_turn):
+            a = groups.setdefault(name, dict(ms=0.0, launches=0, pairs=0.0))
+            a["ms"] += float(r["ms"]); a["pairs"] += float(r["pairs"]); a["launches"] += 1
+        kernels = [dict(kernel=k, launches=a["launches"], avg_ms=a["ms"] / a["launches"], total_ms=a["ms"],
+                        pairs_per_launch=a["pairs"] / a["launches"])
+                   for k, a in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])]
+        views = len(getattr(job, "cameras", wl["cams"]))
         out = {
             "metric": METRIC, "value": rays / dt / 1e6, "unit": "Mrays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / steps * 1e3,
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32",
             "data": wl.get("data", "synthetic"),
             "config": {"workload": args.workload, "description": wl["desc"], "width": wl["width"],
-                       "height": wl["height"], "views": len(getattr(job, "cameras", wl["cams"])), "triangles": int(wl["mesh"].shape[0] // 3),
+                       "height": wl["height"], "views": views, "triangles": int(wl["mesh"].shape[0] // 3),
                        "passes": wl["passes"], "lights": wl["lights"], "sharding": shard_desc,
                        "trace_mode": ("filtered", "exact", "clustered")[args.trace_mode],
                        "rays_per_step": rays / steps,
@@ -323,37 +412,45 @@ def main():
                        # the reference traces a shadow ray per light for every pixel in every pass, dead
                        # pixels included; the value above counts only the rays this build traces
                        "rays_per_step_reference_accounting": tot[0] / steps + float(wl["width"]) * wl["height"] *
-                       wl["lights"] * wl["passes"] * len(getattr(job, "cameras", wl["cams"])),
-                       "pairs_per_step": (tot[2] + tot[3]) / steps,
-                       "filter_pass_rate": (tot[4] + tot[5]) / max(tot[2] + tot[3], 1.0),
-                       "slow_steps_per_step": {"closest": tot[6] / steps, "shadow": tot[7] / steps}},
-            "pairs_per_s": (tot[2] + tot[3]) / dt,
+                       wl["lights"] * wl["passes"] * views,
+                       "pairs_decided_per_step": (tot[2] + tot[3]) / steps,
+                       "frame_crc32": frame_crc},
+            # what the brute-force loop would have to sustain to decide the same pairs in the same time
+            "equivalent_bruteforce_tflops": (tot[2] + tot[3]) * FLOP_PER_TEST / dt / 1e12,
             "stage_ms_per_step_rank0": {"raygen": stage_ms[0] / steps, "intersect": stage_ms[1] / steps,
                                         "color": stage_ms[2] / steps},
-            "roofline": roofline,
+            "roofline": None,
             "kernels_rank0": kernels[:6],
         }
-        # raygen: 14 planes of one float written per ray, nothing read
-        if stage_ms[0] > 0:
+        if on_gpu and stage_ms[0] > 0:
+            # raygen: 14 planes of one float written per ray, nothing read
             frames = max(1, len(getattr(job, "mine", [0])))  # raygen launches per step on this rank
             gbs = RAY_PLANE_BYTES * g.num_rays * steps * frames / (stage_ms[0] * 1e-3) / 1e9
-            rg_traffic, _ = measured_traffic(args.workload if world == 1 else None, ["rtk::raygen_kernel"])
-            out["roofline_raygen"] = {"bound": "hbm", "kernel": "raygen_kernel", "achieved": gbs, "peak": PEAK_HBM_GBS,
-                                      "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": rg_traffic,
+            pmc = committed_counters(args.workload if world == 1 else None)[0].get("rtk::raygen_kernel", {})
+            out["roofline_raygen"] = {"bound": "hbm", "kernel": "rtk::raygen_kernel", "achieved": gbs, "peak": PEAK_HBM_GBS,
+                                      "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": pmc.get("hbm_bytes_per_launch"),
                                       "avg_launch_ms": stage_ms[0] / (steps * frames),
                                       "bytes_per_launch": RAY_PLANE_BYTES * g.num_rays}
-        if world == 1 and wl["kind"] == "tiles" and args.trace_mode == 2 and not args.no_per_pair:
-            # after the timed region: the same frame in the per-pair mode, for the roofline of the
-            # brute-force loop itself (the general filter of the bounce passes does its 20 operations on
-            # every pair: frac < 1; the shared-origin filter of the primary pass has a one-operation first level)
-            out["roofline_per_pair_mode"] = per_pair_roofline(g, job, wl, args.trace_mode)
+        if on_gpu and world == 1 and args.trace_mode == 2 and not args.no_kernel_rooflines:
+            per_kernel = kernel_rooflines(g, job, wl, args.workload)
+            if per_kernel:
+                dom = dict(per_kernel[0])
+                dom["note"] = ("the kernel with the most time per frame; FP32 vector ALU work, no MFMA; achieved = executed VALU "
+                               "wave-instructions per launch (committed PMC summary) / the launch's duration from the hipEvent "
+                               "pair around it on the library's stream, kernels of a bounce pass one after the other; peak = "
+                               "1024 SIMDs x 0.25 wave-instructions per clock (16 lanes per SIMD) x 2.4 GHz")
+                out["roofline"] = dom
+                out["roofline_kernels"] = per_kernel
+            if wl["kind"] == "tiles":
+                out["roofline_exact_mode"] = exact_mode_roofline(g, job, wl)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    g.close()
+    if on_gpu:
+        g.close()
 
 
 if __name__ == "__main__":

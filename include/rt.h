@@ -82,10 +82,12 @@ typedef enum rt_status {
  *                       (ray, triangle) pair, followed by the reference's own
  *                       Moller-Trumbore arithmetic on the few pairs that pass.
  *   RT_TRACE_EXACT    : the reference's arithmetic on every pair (validation).
- *   RT_TRACE_CLUSTERED: (the default) as FILTERED, but bounce rays first go through two
- *                       cheaper conservative sweeps -- one dot product per pair against the
- *                       triangle's plane, and one sphere test per cluster of 32 triangles --
- *                       and only pairs these cannot reject reach the edge filter.
+ *   RT_TRACE_CLUSTERED: (the default) as FILTERED, but bounce rays visit far fewer pairs:
+ *                       a front-to-back walk over the cells of a uniform grid in space
+ *                       finds the pairs whose ray meets the triangle's plane at a fair
+ *                       angle and stops behind the closest hit; a sweep over lists of
+ *                       triangles by plane normal finds the grazing pairs the walk's
+ *                       stopping rule cannot vouch for.  Only these reach the edge filter.
  */
 typedef enum rt_trace_mode {
     RT_TRACE_FILTERED  = 0,
@@ -229,10 +231,13 @@ int rt_get_counters(rt_ctx *ctx, uint64_t counters[8]);
  * the last rt_kernel_log / rt_create (at most the 1024 most recent launches).
  *   stage : 1 = closest-hit traversal (rt_intersect), 2 = shadow traversal + shading (rt_color)
  *   form  : 0 = filter for arbitrary rays, 1 = filter for rays sharing an origin,
- *           2 = clustered traversal of arbitrary rays (its two sweeps run side by side on two
- *           streams and share one record, from before the first to after the second; one record
- *           each when RT_SWEEPS_IN_TURN=1 or without band lists), 3 = rays sharing an origin,
- *           each against the triangle list of its direction cell
+ *           2 = clustered traversal of arbitrary rays: its band sweep and its walk over cells run
+ *           side by side on two streams and share this one record, from before the first kernel
+ *           to after the last; with RT_OPT_SWEEPS_IN_TURN (or without band lists) they run one
+ *           after the other and form 2 is the band sweep alone, followed by 4 = the walk over
+ *           cells, one lane per ray, and 5 = the long walks it handed over, one wavefront per ray
+ *           (4 and 5 report 0 pairs), 3 = rays sharing an origin, each against the triangle list
+ *           of its direction cell
  *   rays_per_lane : 1, 2 or 4
  *   rays  : rays the launch traversed
  *   pairs : (ray, triangle) pairs = rays x triangles (x lights for stage 2; an

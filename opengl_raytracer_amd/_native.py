@@ -88,6 +88,27 @@ class RtError(RuntimeError):
         self.code = code
 
 
+def _share_hip_runtime_with_torch():
+    """A process can use the GPU through ONE copy of the HIP runtime only: a second copy finds no
+    device.  PyTorch's ROCm wheels carry their own (torch/lib/libamdhip64.so, soname libamdhip64.so.7,
+    which librt_hip.so's dependency of that name resolves to once it is loaded).  So when torch is
+    installed but not imported yet, its copy is loaded here first -- without importing torch -- and
+    a later `import torch` in the same process finds the runtime it expects."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
 def load():
     """Loads librt_hip.so and sets the prototypes.  Raises if it is missing."""
     global _lib
@@ -97,6 +118,7 @@ def load():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `make -C opengl_raytracer_amd/csrc` "
             "(or __graft_entry__.build()); there is no CPU fallback")
+    _share_hip_runtime_with_torch()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol

@@ -1069,8 +1069,9 @@ static int launch_traverse_clustered(rt_ctx *c, TraverseParams p, int n_upper, i
     const unsigned long long tris = (unsigned long long)(p.tri_end - p.tri_begin);
     size_t ks;
     // The two sweeps are two kernels that only meet in `best` (atomicMin).  With the band lists they run
-    // side by side, the walk over the cells in space on the side stream, and the log holds one record for
-    // the pair; otherwise one after the other, one record each (the second with 0 pairs).
+    // side by side, the walk over the cells in space on the side stream, and the log holds one record
+    // (form 2) for all of it; otherwise one after the other, one record per kernel: the band sweep
+    // (form 2), the walk (form 4) and its long walks (form 5), the last two with 0 pairs.
     const bool fork = c->band_entries && sweeps_side_by_side(c);
     if (fork) {
         // rt_intersect forks before it groups the rays for the band sweep (the walk does not wait for that)
@@ -1107,7 +1108,7 @@ static int launch_traverse_clustered(rt_ctx *c, TraverseParams p, int n_upper, i
     HIPCHK(c, hipGetLastError());
     if (!fork) {
         if (int r = klog_end(c, ks)) return r;
-        if (int r = klog_begin(c, 1, 2, 1, false, n_slot, 0ull, 0ull, &ks)) return r;
+        if (int r = klog_begin(c, 1, 4, 1, false, n_slot, 0ull, 0ull, &ks)) return r;
     }
     // ---- the walk over the cells in space: well-conditioned pairs
     {
@@ -1119,6 +1120,10 @@ static int launch_traverse_clustered(rt_ctx *c, TraverseParams p, int n_upper, i
         HIPCHK(c, hipMemsetAsync(c->walk_count_d, 0, sizeof(int), st));
         hipLaunchKernelGGL(traverse_voxel_kernel, dim3(cdiv(n_upper, BLOCK)), dim3(BLOCK), 0, st, p);
         HIPCHK(c, hipGetLastError());
+        if (!fork) {
+            if (int r = klog_end(c, ks)) return r;
+            if (int r = klog_begin(c, 1, 5, 1, false, n_slot, 0ull, 0ull, &ks)) return r;
+        }
         // the long walks, one wavefront each (their number is only known on the device)
         const int long_blocks = list_blocks(n_upper, BLOCK / 64);
         hipLaunchKernelGGL(traverse_voxel_long_kernel, dim3(long_blocks < 2048 ? long_blocks : 2048), dim3(BLOCK), 0, st, p);

@@ -313,15 +313,15 @@ def test_sorted_ray_paths_against_oracle(rt, oracle_mod, grid_bits):
         assert_same("sorted paths", g, c)
         assert_same_pixels("sorted paths", g, c)
         log = g.kernel_log()
-        # the bounce passes ran as two kernels: band sweep (over direction cells, or streaming with 4 rays
-        # per lane), then sphere sweep
+        # a bounce pass is a band sweep (over direction cells, or streaming) and a walk over cells in space
         forms = [(int(r["form"]), int(r["rays_per_lane"])) for r in log if int(r["stage"]) == 1]
         if grid_bits == 0:
-            assert forms[0] == (1, 4) and forms.count((2, 1)) == 4, forms
+            # without band lists the kernels run one after the other: one record each
+            assert forms == [(1, 4)] + [(2, 1), (4, 1), (5, 1)] * 2, forms
         else:
-            # one record per bounce pass when the two sweeps run side by side on two streams (the default),
-            # two when they run in turn (RT_OPT_SWEEPS_IN_TURN)
-            assert forms in ([(3, 1), (2, 1), (2, 1)], [(3, 1), (2, 1), (2, 1), (2, 1), (2, 1)]), forms
+            # one record per bounce pass when the kernels run side by side on two streams (the default),
+            # three when they run in turn (RT_OPT_SWEEPS_IN_TURN)
+            assert forms in ([(3, 1), (2, 1), (2, 1)], [(3, 1)] + [(2, 1), (4, 1), (5, 1)] * 2), forms
 
 
 # -- error behaviour -----------------------------------------------------------------------
@@ -363,11 +363,11 @@ def test_stage_timers_and_counters(rt):
         assert g.stage_ms() == [0.0, 0.0, 0.0]
         log = g.kernel_log()
         # fresh rays share the camera origin (direction cells), shadow rays the light; bounce rays: clustered,
-        # one record for the band sweep and the sphere sweep running side by side (two records when they run
-        # in turn, RT_OPT_SWEEPS_IN_TURN: the band sweep's with the pass's pairs, the sphere sweep's with 0)
+        # one record for the band sweep and the walk over cells running side by side (three records when they
+        # run in turn, RT_OPT_SWEEPS_IN_TURN: the band sweep's with the pass's pairs, the walk's two with 0)
         forms = [(int(r["stage"]), int(r["form"])) for r in log]
-        assert forms in ([(1, 3), (2, 3), (1, 2), (2, 3)], [(1, 3), (2, 3), (1, 2), (1, 2), (2, 3)]), forms
-        with_pairs = [0, 1, 2, 3] if len(forms) == 4 else [0, 1, 2, 4]
+        assert forms in ([(1, 3), (2, 3), (1, 2), (2, 3)], [(1, 3), (2, 3), (1, 2), (1, 4), (1, 5), (2, 3)]), forms
+        with_pairs = [0, 1, 2, 3] if len(forms) == 4 else [0, 1, 2, 5]
         assert (log["ms"] > 0).all() and (log["pairs"][with_pairs] > 0).all()
         assert g.kernel_log().shape[0] == 0
 

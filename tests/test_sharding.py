@@ -92,3 +92,29 @@ def test_tile_assignment_covers_every_row_once():
     assert sharding.choose_tile_rows(2160, 8) == 15
     assert sharding.choose_tile_rows(2160, 1) == 16
     assert sharding.choose_tile_rows(2160, 2) == 15
+
+
+def _run_bench(*extra):
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0",
+                          "--renderer", "oracle", "--backend", "gloo", "--no-cpu-baseline", *extra],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_starts_its_own_ranks_and_cuts_one_frame_into_tiles():
+    """bench.py --gpus 2 without a launcher around it: two ranks, one frame in row tiles by default
+    (strong scaling), the same pixels as one rank; --sharding batch renders a frame per rank (weak)."""
+    one = _run_bench("--workload", "sword_800_p2")
+    two = _run_bench("--workload", "sword_800_p2", "--gpus", "2")
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert two["scaling"] == "strong" and "tiles" in two["config"]["sharding"]
+    assert two["config"]["frame_crc32"] == one["config"]["frame_crc32"] is not None
+    assert two["config"]["rays_per_step"] == one["config"]["rays_per_step"]
+    weak = _run_bench("--workload", "sword_800_p2", "--gpus", "2", "--sharding", "batch")
+    assert weak["scaling"] == "weak" and weak["config"]["rays_per_step"] == 2 * one["config"]["rays_per_step"]

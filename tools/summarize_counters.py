@@ -17,10 +17,10 @@ def short(n):
 
 lines = []
 stats = list(csv.DictReader(open(f"{base}/trace/t_kernel_stats.csv")))
-lines.append("== rocprofv3 --kernel-trace --stats (python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-per-pair) ==")
+lines.append("== rocprofv3 --kernel-trace --stats (python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --sweeps-in-turn) ==")
 traffic = {}
 lines.append(f"{'kernel':70s} {'calls':>6s} {'avg_us':>12s} {'total_ms':>10s} {'%':>6s}")
-for r in stats[:14]:
+for r in stats[:24]:
     lines.append(f"{short(r['Name'])[:70]:70s} {r['Calls']:>6s} {float(r['AverageNs'])/1e3:12.1f} "
                  f"{float(r['TotalDurationNs'])/1e6:10.2f} {float(r['Percentage']):6.2f}")
 dur = {short(r["Name"]): (float(r["AverageNs"]) * 1e-9, int(r["Calls"])) for r in stats}
@@ -46,14 +46,17 @@ for k, v in agg.items():
                  f"  SQ_WAVES {per.get('SQ_WAVES',0):.4g}  SQ_INSTS_VALU_MFMA_F32 {per.get('SQ_INSTS_VALU_MFMA_F32',0):.4g}")
     clk = per.get("GRBM_GUI_ACTIVE", 0.0) / 8.0 / t if t == t and t > 0 else float("nan")
     lines.append(f"   VALU wave-instructions/s {valu/t/1e9:.1f} G   effective clock (GRBM_GUI_ACTIVE/8/t) {clk/1e9:.2f} GHz"
-                 f"   VALU issue utilisation {valu/t/(1024*0.5*clk)*100 if clk==clk and clk>0 else float('nan'):.1f} % of 1024 SIMDs x 0.5 inst/clk")
+                 f"   VALU issue utilisation {valu/t/(1024*0.25*clk)*100 if clk==clk and clk>0 else float('nan'):.1f} % of 1024 SIMDs x 0.25 inst/clk")
     # FETCH_SIZE / WRITE_SIZE are reported in KiB; FETCH_SIZE counts 128-B reads as 64 B on gfx950 (x2)
     lines.append(f"   FETCH_SIZE {per.get('FETCH_SIZE',0)*1024/1e6:.1f} MB raw (x2 for wide coalesced reads on gfx950 = {per.get('FETCH_SIZE',0)*2048/1e6:.1f} MB)"
                  f"   WRITE_SIZE {per.get('WRITE_SIZE',0)*1024/1e6:.1f} MB   -> {(per.get('FETCH_SIZE',0)*2048+per.get('WRITE_SIZE',0)*1024)/t/1e12:.3f} TB/s HBM")
     if "FETCH_SIZE" in per and "WRITE_SIZE" in per:
         traffic[k] = {"hbm_bytes_per_launch": per["FETCH_SIZE"] * 2048 + per["WRITE_SIZE"] * 1024,
                       "launches": n, "avg_ms": t * 1e3, "valu_wave_insts_per_launch": valu,
-                      "valu_issue_frac": (valu / t / (1024 * 0.5 * clk)) if clk == clk and clk > 0 else None}
+                      "valu_issue_frac": (valu / t / (1024 * 0.25 * clk)) if clk == clk and clk > 0 else None,
+                      "valu_busy_quadcycles_per_launch": per.get("SQ_ACTIVE_INST_VALU")}
+    lines.append(f"   SQ_ACTIVE_INST_VALU {per.get('SQ_ACTIVE_INST_VALU',0):.4g} quad-cycles = {per.get('SQ_ACTIVE_INST_VALU',0)/valu if valu else 0:.2f} per VALU instruction"
+                 f"   SQ_WAVE_CYCLES {per.get('SQ_WAVE_CYCLES',0):.4g}  SQ_WAIT_INST_ANY {per.get('SQ_WAIT_INST_ANY',0):.4g}")
     lines.append(f"   SQ_LDS_IDX_ACTIVE {per.get('SQ_LDS_IDX_ACTIVE',0):.4g}  SQ_LDS_BANK_CONFLICT {per.get('SQ_LDS_BANK_CONFLICT',0):.4g}")
 open(out, "w").write("\n".join(lines) + "\n")
 json.dump({"source": os.path.basename(out), "workload": "soup64k_4k_p6",
