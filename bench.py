@@ -281,6 +281,8 @@ def main():
                     help="the two kernels of a bounce pass one after the other in the timed region too (for profiles)")
     ap.add_argument("--sharding", choices=("auto", "batch", "tiles"), default="auto",
                     help="N > 1: one frame in row tiles (default for single-frame workloads), or whole frames per rank")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="context option (a key of opengl_raytracer_amd._native.OPTIONS), e.g. --opt grid_bits=8")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the gather (nccl = RCCL)")
     ap.add_argument("--renderer", choices=("hip", "oracle"), default="hip",
                     help="oracle: the CPU restatement stands in for the GPU (tests of this program's launcher only)")
@@ -312,7 +314,8 @@ def main():
     wl = workload(args.workload)
     if on_gpu:
         import opengl_raytracer_amd as rt
-        g = rt.RayTracer(wl["width"], wl["height"], device=local_rank)
+        opts = {k: int(v) for k, v in (o.split("=", 1) for o in args.opt)}
+        g = rt.RayTracer(wl["width"], wl["height"], device=local_rank, options=opts)
         g.set_trace_mode(args.trace_mode)
         if args.sweeps_in_turn:
             g.set_option("sweeps_in_turn", 1)
@@ -406,7 +409,7 @@ def main():
             "config": {"workload": args.workload, "description": wl["desc"], "width": wl["width"],
                        "height": wl["height"], "views": views, "triangles": int(wl["mesh"].shape[0] // 3),
                        "passes": wl["passes"], "lights": wl["lights"], "sharding": shard_desc,
-                       "trace_mode": ("filtered", "exact", "clustered")[args.trace_mode],
+                       "trace_mode": ("filtered", "exact", "clustered")[args.trace_mode], "options": args.opt,
                        "rays_per_step": rays / steps,
                        "closest_hit_rays_per_step": tot[0] / steps, "shadow_rays_per_step": tot[1] / steps,
                        # the reference traces a shadow ray per light for every pixel in every pass, dead

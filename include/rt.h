@@ -156,6 +156,9 @@ int rt_set_trace_mode(rt_ctx *ctx, int mode /* rt_trace_mode */);
  *   RT_OPT_WALK_BUDGET      loop steps a wavefront of that walk spends, one ray per lane, before the walks
  *                           still under way are handed to the kernel that gives each a wavefront of its
  *                           own; 0 = chosen from the number of rays (default: 96 from 2^19 rays on, else 48)
+ *   RT_OPT_FAIL_NEXT_STAGE  for tests of a caller's error handling: with a value other than 0 the next
+ *                           rt_intersect or rt_color fails with RT_ERR_HIP after it has begun (its timing
+ *                           events open, nothing enqueued) and the option returns to 0
  * RT_OPT_GRID_BITS, RT_OPT_BAND_LIST_MAX and RT_OPT_VOXEL_RES decide what rt_set_mesh builds: after
  * setting one of them the context has no mesh until the next rt_set_mesh. */
 typedef enum rt_option {
@@ -165,7 +168,8 @@ typedef enum rt_option {
     RT_OPT_SWEEPS_IN_TURN   = 3,
     RT_OPT_BAND_LIST_MAX    = 4,
     RT_OPT_VOXEL_RES        = 5,
-    RT_OPT_WALK_BUDGET      = 6
+    RT_OPT_WALK_BUDGET      = 6,
+    RT_OPT_FAIL_NEXT_STAGE  = 7
 } rt_option;
 int rt_set_option(rt_ctx *ctx, int option /* rt_option */, long long value);
 

@@ -117,12 +117,12 @@ struct rt_ctx {
     unsigned int *grid_off[1 + RT_MAX_LIGHTS] = {};
     int *grid_entries[1 + RT_MAX_LIGHTS] = {};
     size_t grid_cap[1 + RT_MAX_LIGHTS] = {};
+    int grid_level[1 + RT_MAX_LIGHTS] = {};  // cells per axis = 2^level of that origin's lists (<= grid_bits)
+    int grid_uses[1 + RT_MAX_LIGHTS] = {};   // launches those lists have served
     void *scan_temp = nullptr;
     size_t scan_temp_bytes = 0;
     rtg::SlotView *slot_views_d = nullptr; // scratch of the list builder, one per slot
-    unsigned int *build_work_d = nullptr;  // ... its (slot, top cell) pairs, and their number at [0] of build_count_d
-    unsigned int *build_count_d = nullptr;
-    unsigned int *build_item_d = nullptr;  // per pair: cells reached, then their exclusive scan
+    unsigned long long *build_count_d = nullptr; // [0] pairs the list builder counted, [1] its fault flag
     unsigned int *build_keys_d = nullptr, *build_keys_out_d = nullptr; // (cell, slot) pairs before / after the sort
     int *build_vals_d = nullptr;
     size_t build_pairs_cap = 0;
@@ -183,6 +183,7 @@ struct rt_ctx {
     // tuning, per context (rt_set_option)
     int sort_min_rays = 131072;      // launches with at least this many rays sort them
     int cluster_min_tris = 1024;     // smaller meshes: bounce rays take the per-pair filter
+    bool fail_next_stage = false;    // RT_OPT_FAIL_NEXT_STAGE
     bool sweeps_in_turn = false;     // the two sweeps of a clustered bounce pass one after the other
     unsigned long long band_list_max = 0xffffff00ull; // longer band lists are not built (32-bit positions)
     // 64-bit totals of the list builders
@@ -288,6 +289,8 @@ static void free_grid_tables(rt_ctx *c)
         (void)hipFree(c->grid_off[i]); c->grid_off[i] = nullptr;
         (void)hipFree(c->grid_entries[i]); c->grid_entries[i] = nullptr;
         c->grid_cap[i] = 0;
+        c->grid_level[i] = 0;
+        c->grid_uses[i] = 0;
     }
 }
 
@@ -480,9 +483,7 @@ extern "C" void rt_destroy(rt_ctx *c)
     (void)hipFree(c->band_off);
     (void)hipFree(c->band_entries);
     (void)hipFree(c->slot_views_d);
-    (void)hipFree(c->build_work_d);
     (void)hipFree(c->build_count_d);
-    (void)hipFree(c->build_item_d);
     (void)hipFree(c->build_keys_d);
     (void)hipFree(c->build_keys_out_d);
     (void)hipFree(c->build_vals_d);
@@ -582,8 +583,6 @@ extern "C" int rt_set_mesh(rt_ctx *c, const rt_vertex *vertices, int num_vertice
     (void)hipFree(c->band_off); c->band_off = nullptr;
     (void)hipFree(c->band_entries); c->band_entries = nullptr;
     (void)hipFree(c->slot_views_d); c->slot_views_d = nullptr;
-    (void)hipFree(c->build_work_d); c->build_work_d = nullptr;
-    (void)hipFree(c->build_item_d); c->build_item_d = nullptr;
     c->num_vertices = num_vertices;
     c->num_tris = num_vertices / 3;
     // record arrays are padded to whole tiles so that a tile copy never leaves the allocation
@@ -808,6 +807,9 @@ extern "C" int rt_set_option(rt_ctx *c, int option, long long value)
         if (value < 0 || value > 0xffffff00ll) break;
         c->band_list_max = (unsigned long long)value;
         c->have_mesh = false; // the lists are built by rt_set_mesh
+        return RT_OK;
+    case RT_OPT_FAIL_NEXT_STAGE:
+        c->fail_next_stage = value != 0;
         return RT_OK;
     case RT_OPT_WALK_BUDGET:
         if (value < 0 || value > (1 << 24)) break;
@@ -1159,68 +1161,57 @@ static int build_grid(rt_ctx *c, int which, const rtf::ConeRec *cones, const rtf
     if (!c->grid_bits || !c->num_slots) return RT_OK;
     const double reach_max = rtf::cone_reach_max(origin, c->center, c->radius);
     const double extent = rtf::scene_extent(origin, c->center, c->radius);
-    const size_t ncells = (size_t)1 << (2 * c->grid_bits);
-    if (!c->grid_off[which]) HIPCHK(c, hipMalloc(&c->grid_off[which], (ncells + 2) * sizeof(unsigned int)));
+    // Lists of cells of 2^grid_bits per axis, or one level coarser for an origin that moves with every
+    // launch -- its previous lists served one launch only -- when the frame is small against the mesh:
+    // building costs by the (slot, cell) pair, four times fewer a level up, and a launch of few rays
+    // per slot does not earn the finer lists back.
+    int level = c->grid_bits;
+    if (c->grid_level[which] && c->grid_uses[which] <= 1 && c->grid_bits > 4 &&
+        (long long)c->n_rays < 16ll * (long long)c->num_slots)
+        level = c->grid_bits - 1;
+    c->grid_level[which] = level;
+    c->grid_uses[which] = 0;
+    const size_t ncells = (size_t)1 << (2 * level);
+    if (!c->grid_off[which])
+        HIPCHK(c, hipMalloc(&c->grid_off[which], (((size_t)1 << (2 * c->grid_bits)) + 2) * sizeof(unsigned int)));
     const float4 *cn = reinterpret_cast<const float4 *>(cones);
     if (!c->slot_views_d) HIPCHK(c, hipMalloc(&c->slot_views_d, (size_t)c->num_slots * sizeof(rtg::SlotView)));
     hipLaunchKernelGGL(slot_view_kernel, dim3(cdiv(c->num_slots, BLOCK)), dim3(BLOCK), 0, c->stream, cn, c->num_slots,
                        recs, (const int *)c->slot_d, (const rt_vertex *)c->verts, origin[0], origin[1], origin[2], extent,
                        reach_max, c->slot_views_d);
     HIPCHK(c, hipGetLastError());
-    const size_t work_cap = (size_t)c->num_slots * BUILD_TOP_CELLS;
-    if (!c->build_work_d) HIPCHK(c, hipMalloc(&c->build_work_d, work_cap * sizeof(unsigned int)));
-    if (!c->build_item_d) HIPCHK(c, hipMalloc(&c->build_item_d, (work_cap + 1) * sizeof(unsigned int)));
-    if (!c->build_count_d) HIPCHK(c, hipMalloc(&c->build_count_d, sizeof(unsigned int)));
-    HIPCHK(c, hipMemsetAsync(c->build_count_d, 0, sizeof(unsigned int), c->stream));
-    hipLaunchKernelGGL(grid_top_kernel, dim3(cdiv(c->num_slots, (BLOCK / 64) * TOP_SLOTS_PER_WAVE)), dim3(BLOCK), 0,
-                       c->stream, (const rtg::CellCone *)c->cell_cones_d, (const rtg::SlotView *)c->slot_views_d,
-                       c->num_slots, c->build_work_d, c->build_count_d);
-    HIPCHK(c, hipGetLastError());
-    // a handful of pairs per slot survive: size the walk by their number
-    unsigned int *pairs_h = reinterpret_cast<unsigned int *>(c->count_h + 5);
-    HIPCHK(c, hipMemcpyAsync(pairs_h, c->build_count_d, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    const size_t items = *pairs_h;
-    const dim3 grid(cdiv((long long)items + 1, BLOCK));
-    hipLaunchKernelGGL((grid_walk_kernel<false>), grid, dim3(BLOCK), 0, c->stream,
-                       (const rtg::CellCone *)c->cell_cones_d, c->grid_bits, (const rtg::SlotView *)c->slot_views_d,
-                       (const unsigned int *)c->build_work_d, (const unsigned int *)c->build_count_d, c->build_item_d,
-                       (const unsigned int *)nullptr, (unsigned int *)nullptr, (int *)nullptr);
-    HIPCHK(c, hipGetLastError());
-    {
-        unsigned long long total64 = 0;
-        if (int r = sum_counts(c, c->build_item_d, items + 1, &total64)) return r;
-        if (total64 > 0xffffff00ull)
-            return fail(c, RT_ERR_NOMEM, "direction cells: %llu list entries for one origin exceed the 32-bit list "
-                        "positions; lower RT_OPT_GRID_BITS", total64);
-    }
-    // exclusive scan in place over items + 1 entries: the last one receives the number of pairs
-    {
-        size_t bytes = 0;
-        HIPCHK(c, rocprim::exclusive_scan(nullptr, bytes, c->build_item_d, c->build_item_d, 0u, items + 1,
-                                          rocprim::plus<unsigned int>(), c->stream));
-        if (bytes > c->build_temp_bytes) {
-            (void)hipFree(c->build_temp_d);
-            c->build_temp_d = nullptr;
-            c->build_temp_bytes = bytes + bytes / 4 + 256;
-            HIPCHK(c, hipMalloc(&c->build_temp_d, c->build_temp_bytes));
+    // every (cell, slot) pair in one launch, in no particular order; the launch counts the pairs it had
+    // no room for too, and runs again with larger arrays when there were any
+    if (!c->build_count_d) HIPCHK(c, hipMalloc(&c->build_count_d, 2 * sizeof(unsigned long long)));
+    size_t total = 0;
+    for (int attempt = 0;; attempt++) {
+        if (!c->build_keys_d) {
+            if (c->build_pairs_cap < (size_t)c->num_slots * 8 + 4096) c->build_pairs_cap = (size_t)c->num_slots * 8 + 4096;
+            HIPCHK(c, hipMalloc(&c->build_keys_d, c->build_pairs_cap * sizeof(unsigned int)));
+            HIPCHK(c, hipMalloc(&c->build_keys_out_d, c->build_pairs_cap * sizeof(unsigned int)));
+            HIPCHK(c, hipMalloc(&c->build_vals_d, c->build_pairs_cap * sizeof(int)));
         }
-        bytes = c->build_temp_bytes;
-        HIPCHK(c, rocprim::exclusive_scan(c->build_temp_d, bytes, c->build_item_d, c->build_item_d, 0u, items + 1,
-                                          rocprim::plus<unsigned int>(), c->stream));
-    }
-    unsigned int *total_h = reinterpret_cast<unsigned int *>(c->count_h + 4);
-    HIPCHK(c, hipMemcpyAsync(total_h, c->build_item_d + items, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    const size_t total = *total_h;
-    if (total > c->build_pairs_cap || !c->build_keys_d) {
+        HIPCHK(c, hipMemsetAsync(c->build_count_d, 0, 2 * sizeof(unsigned long long), c->stream));
+        hipLaunchKernelGGL(grid_list_kernel, dim3(cdiv(c->num_slots, GRID_LIST_WAVES * 64)), dim3(GRID_LIST_WAVES * 64), 0,
+                           c->stream, (const rtg::CellCone *)c->cell_cones_d, level,
+                           (const rtg::SlotView *)c->slot_views_d, c->num_slots, c->build_keys_d, c->build_vals_d,
+                           c->build_count_d, (unsigned long long)c->build_pairs_cap,
+                           reinterpret_cast<int *>(c->build_count_d + 1));
+        HIPCHK(c, hipGetLastError());
+        unsigned long long *res_h = reinterpret_cast<unsigned long long *>(c->count_h + 4);
+        HIPCHK(c, hipMemcpyAsync(res_h, c->build_count_d, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (res_h[1] != 0) return fail(c, RT_ERR_HIP, "direction cells: the list builder ran out of stack");
+        if (res_h[0] > 0xffffff00ull)
+            return fail(c, RT_ERR_NOMEM, "direction cells: %llu list entries for one origin exceed the 32-bit list "
+                        "positions; lower RT_OPT_GRID_BITS", res_h[0]);
+        total = (size_t)res_h[0];
+        if (total <= c->build_pairs_cap) break;
+        if (attempt) return fail(c, RT_ERR_HIP, "direction cells: the list builder counted %zu pairs twice over", total);
         (void)hipFree(c->build_keys_d); c->build_keys_d = nullptr;
         (void)hipFree(c->build_keys_out_d); c->build_keys_out_d = nullptr;
         (void)hipFree(c->build_vals_d); c->build_vals_d = nullptr;
         c->build_pairs_cap = total + total / 4 + 1024;
-        HIPCHK(c, hipMalloc(&c->build_keys_d, c->build_pairs_cap * sizeof(unsigned int)));
-        HIPCHK(c, hipMalloc(&c->build_keys_out_d, c->build_pairs_cap * sizeof(unsigned int)));
-        HIPCHK(c, hipMalloc(&c->build_vals_d, c->build_pairs_cap * sizeof(int)));
     }
     if (total > c->grid_cap[which] || !c->grid_entries[which]) {
         (void)hipFree(c->grid_entries[which]);
@@ -1228,14 +1219,9 @@ static int build_grid(rt_ctx *c, int which, const rtf::ConeRec *cones, const rtf
         c->grid_cap[which] = total + total / 4 + 1024;
         HIPCHK(c, hipMalloc(&c->grid_entries[which], c->grid_cap[which] * sizeof(int)));
     }
-    hipLaunchKernelGGL((grid_walk_kernel<true>), grid, dim3(BLOCK), 0, c->stream,
-                       (const rtg::CellCone *)c->cell_cones_d, c->grid_bits, (const rtg::SlotView *)c->slot_views_d,
-                       (const unsigned int *)c->build_work_d, (const unsigned int *)c->build_count_d,
-                       (unsigned int *)nullptr, (const unsigned int *)c->build_item_d, c->build_keys_d, c->build_vals_d);
-    HIPCHK(c, hipGetLastError());
     if (total) {
         // by cell; the list "everywhere" has key num_cells: one bit more than the cells need
-        const unsigned int key_bits = 2u * (unsigned int)c->grid_bits + 1u;
+        const unsigned int key_bits = 2u * (unsigned int)level + 1u;
         size_t bytes = 0;
         HIPCHK(c, rocprim::radix_sort_pairs(nullptr, bytes, c->build_keys_d, c->build_keys_out_d, c->build_vals_d,
                                             c->grid_entries[which], total, 0, key_bits, c->stream));
@@ -1262,7 +1248,8 @@ static int launch_traverse_grid(rt_ctx *c, TraverseParams p, int n_upper, int n_
     if (n_upper <= 0) return RT_OK;
     p.grid_off = c->grid_off[which];
     p.grid_entries = c->grid_entries[which];
-    p.grid_bits = c->grid_bits;
+    p.grid_bits = c->grid_level[which];
+    c->grid_uses[which]++;
     p.num_slots = c->num_slots;
     size_t ks;
     if (int r = klog_begin(c, stage, 3, 1, false, n_slot, (unsigned long long)n_upper, (unsigned long long)c->num_tris, &ks))
@@ -1372,6 +1359,10 @@ extern "C" int rt_intersect(rt_ctx *c)
     StageScope scope{c, 0};
     if (int r = stage_begin(c, 1, &scope.slot)) return r;
     scope.open = true;
+    if (c->fail_next_stage) {
+        c->fail_next_stage = false;
+        return fail(c, RT_ERR_HIP, "rt_intersect: failure asked for through RT_OPT_FAIL_NEXT_STAGE");
+    }
     if (c->n_rays > 0) {
         const bool shared = c->rays_share_camera_origin;
         const int *list = nullptr, *count = nullptr;
@@ -1460,6 +1451,10 @@ extern "C" int rt_color(rt_ctx *c)
     StageScope scope{c, 0};
     if (int r = stage_begin(c, 2, &scope.slot)) return r;
     scope.open = true;
+    if (c->fail_next_stage) {
+        c->fail_next_stage = false;
+        return fail(c, RT_ERR_HIP, "rt_color: failure asked for through RT_OPT_FAIL_NEXT_STAGE");
+    }
     if (c->n_rays > 0) {
         if (c->num_lights == 0) {
             // no light: `shadowed` stays true for every pixel (raycol_cs.glsl:28-32, 82)
@@ -1685,7 +1680,11 @@ extern "C" int rt_kernel_log(rt_ctx *c, rt_kernel_record *out, int max, int *n)
         rt_kernel_record r = c->klog_rec[slot];
         if (c->klog_nslot[slot] >= 0) r.rays = (unsigned long long)n_h[c->klog_nslot[slot]];
         r.pairs = r.rays * r.pairs; // triangles per ray until now
-        HIPCHK(c, hipEventElapsedTime(&r.ms, c->klog_ev[slot].a, c->klog_ev[slot].b));
+        // (a launch that failed half-way left its record open: reported with 0 ms)
+        if (hipEventElapsedTime(&r.ms, c->klog_ev[slot].a, c->klog_ev[slot].b) != hipSuccess) {
+            (void)hipGetLastError();
+            r.ms = 0.0f;
+        }
         out[w++] = r;
     }
     *n = w;

@@ -1026,110 +1026,207 @@ constexpr int BUILD_TOP_CELLS = 1 << (2 * BUILD_TOP_LEVEL);
 constexpr unsigned int BUILD_EVERYWHERE = 0xffu;
 constexpr int BUILD_STACK = 3 * (rtg::MAX_BITS - BUILD_TOP_LEVEL) + 8; // entries a walk can have pending
 
-// Step 1 of the list build, once per origin: the (slot, top cell) pairs worth walking.  A wavefront
-// takes TOP_SLOTS_PER_WAVE slots in turn, each against the 64 top cells (one read of the slot's view),
-// gathers the pairs that pass in LDS as slot * 256 + top and appends them to `work` with ONE atomic
-// per wavefront (atomics of a launch on one address are served one after the other); a slot for the
-// list "everywhere" is appended once, with top 255.
-constexpr int TOP_SLOTS_PER_WAVE = 16;
-__global__ __launch_bounds__(BLOCK) void grid_top_kernel(const rtg::CellCone *__restrict__ cells,
-                                                         const rtg::SlotView *__restrict__ views, int num_slots,
-                                                         unsigned int *__restrict__ work,
-                                                         unsigned int *__restrict__ work_count)
+// The list build of one origin, one launch: the (cell, slot) pairs of every finest cell a slot must be
+// listed in, appended to keys[] / vals[] in no particular order (they are sorted by cell afterwards;
+// nothing depends on the order inside a cell).  A wavefront takes 64 slots and walks the cells below
+// the whole sphere for all of them TOGETHER: the nodes still to expand -- (slot, cell of some level)
+// -- sit on one stack in LDS, every step the 64 lanes take the 64 topmost nodes, each tests its
+// node's four children against its slot's view (cell_meets_slot: a coarser cell is the union of the
+// four below it, so a failed test drops everything under that child) and the survivors go back on the
+// stack, or, at the finest level, into the wavefront's output buffer.  All lanes do the same work in
+// every step whatever the shape of each slot's walk, which a walk per lane cannot offer.
+//   Depth first, so the stack stays small; and it cannot overflow: a step that could (each node taken
+// leaves up to three more behind than it removes) takes fewer nodes, down to one -- a walk of single
+// nodes from a stack of S adds at most 3 per level below the node on top, under 30 in all, which is
+// the room GRID_LIST_RESERVE keeps free.
+//   A slot for the list "everywhere" is appended once, under cell num_cells.
+//   *cursor counts every pair, stored or not: pairs beyond `cap` are dropped and the host, which
+// reads the total anyway to size the sort, runs the launch again with larger arrays.
+//   Where the data comes from decides the speed (the arithmetic is a tenth of the time): a lane's node is
+// any of the 64 slots at any cell, so 64 lanes reading their own views and cones would touch 64 cache
+// lines with every load instruction, twenty-one instructions a step.  Instead each lane keeps the view
+// of ITS slot in registers and a node's lane fetches the view it needs from that lane (shuffles); the
+// cones of the four children of a node are 192 contiguous bytes, and the wavefront loads those of its
+// 64 nodes as 768 16-byte pieces, consecutive lanes taking consecutive pieces (twelve loads of about a
+// dozen cache lines each), and hands them to the nodes' lanes through 3 KB of LDS, sixteen nodes at a
+// time.  A wavefront needs 11 KB of LDS, so a SIMD holds three or four: the chain from a node to its
+// four tests is long, and only other wavefronts can fill it.
+constexpr int GRID_LIST_WAVES = 4;        // wavefronts per workgroup
+constexpr int GRID_LIST_STACK = 1024;
+constexpr int GRID_LIST_RESERVE = 40;
+constexpr int GRID_LIST_OUT = 256;        // pairs a wavefront gathers before it appends them
+constexpr int GRID_LIST_STAGE_PITCH = 13; // 16-byte pieces per node in the staging area: 12 + 1 against bank conflicts
+__global__ __launch_bounds__(GRID_LIST_WAVES * 64) void grid_list_kernel(
+    const rtg::CellCone *__restrict__ cells, int bits, const rtg::SlotView *__restrict__ views, int num_slots,
+    unsigned int *__restrict__ keys, int *__restrict__ vals, unsigned long long *__restrict__ cursor,
+    unsigned long long cap, int *__restrict__ fault)
 {
-    static_assert(BUILD_TOP_CELLS == 64, "one wavefront per slot");
-    __shared__ unsigned int codes_all[(BLOCK / 64) * TOP_SLOTS_PER_WAVE * 64];
+    static_assert(sizeof(rtg::CellCone) == 48, "four cones are twelve 16-byte pieces");
+    __shared__ unsigned int stack_all[GRID_LIST_WAVES][GRID_LIST_STACK];
+    __shared__ unsigned int okey_all[GRID_LIST_WAVES][GRID_LIST_OUT + 256];
+    __shared__ int oval_all[GRID_LIST_WAVES][GRID_LIST_OUT + 256];
+    __shared__ double2 stage_all[GRID_LIST_WAVES][16 * GRID_LIST_STAGE_PITCH];
     const int wave = threadIdx.x >> 6;
-    const unsigned int top = threadIdx.x & 63u;
-    unsigned int *codes = codes_all + wave * TOP_SLOTS_PER_WAVE * 64;
-    const int first = (blockIdx.x * (BLOCK / 64) + wave) * TOP_SLOTS_PER_WAVE;
+    const int lane = threadIdx.x & 63;
+    const int first = (blockIdx.x * GRID_LIST_WAVES + wave) * 64;
     if (first >= num_slots) return;
-    const rtg::CellCone cc = cells[rtg::level_offset(BUILD_TOP_LEVEL) + top];
-    int n = 0; // wave-uniform
-    for (int i = first; i < min(first + TOP_SLOTS_PER_WAVE, num_slots); i++) {
-        const rtg::SlotView view = views[i];
-        bool keep = false;
-        unsigned int code = (unsigned int)i * 256u + top;
-        if (view.cone != 0) {
-            if (rtg::slot_everywhere(view)) {
-                keep = top == 0;
-                code = (unsigned int)i * 256u + BUILD_EVERYWHERE;
-            } else {
-                keep = rtg::cell_meets_slot(cc, view);
-            }
-        }
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
-        if (keep) codes[n + lanes_below(m)] = code;
-        n += __popcll(m);
-    }
-    if (!n) return;
-    unsigned int base = 0;
-    if (top == 0) base = atomicAdd(work_count, (unsigned int)n);
-    base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
-    for (int k = (int)top; k < n; k += 64) work[base + k] = codes[k];
-}
-
-// Step 2, run twice: one thread per pair walks the cells below its top cell.  FILL = false leaves the
-// number of finest cells it reaches in item_count[t]; FILL = true writes them as (cell, slot) pairs at
-// item_off[t].  The pairs are then sorted by cell (slot order inside a cell: the sort is stable and
-// the walk of a slot's pairs is in slot order only by accident -- nothing depends on the order).
-template <bool FILL>
-__global__ __launch_bounds__(BLOCK) void grid_walk_kernel(const rtg::CellCone *__restrict__ cells, int bits,
-                                                          const rtg::SlotView *__restrict__ views,
-                                                          const unsigned int *__restrict__ work,
-                                                          const unsigned int *__restrict__ work_count,
-                                                          unsigned int *__restrict__ item_count,
-                                                          const unsigned int *__restrict__ item_off,
-                                                          unsigned int *__restrict__ keys, int *__restrict__ vals)
-{
-    // the walk's stack lives in LDS: a register array indexed per lane would be walked lane by lane
-    __shared__ unsigned int stack_all[BUILD_STACK][BLOCK];
-    const unsigned int t = blockIdx.x * BLOCK + threadIdx.x;
-    const unsigned int n_items = *work_count;
-    if (t >= n_items) {
-        if (!FILL && t == n_items) item_count[t] = 0; // the scan's last entry receives the total
-        return;
-    }
-    const unsigned int code = work[t];
-    const int i = (int)(code >> 8);
-    const unsigned int top = code & 0xffu;
+    unsigned int *stack = stack_all[wave]; // node: item | level << 6 | cell << 10
+    unsigned int *okey = okey_all[wave];
+    int *oval = oval_all[wave];
+    double2 *stage = stage_all[wave];
     const unsigned int num_cells = 1u << (2 * bits);
-    unsigned int n = 0;
-    const unsigned int base = FILL ? item_off[t] : 0u;
-    auto emit = [&](unsigned int cell) {
-        if (FILL) {
-            keys[base + n] = cell;
-            vals[base + n] = i;
-        }
-        n++;
+    int sp = 0, n_out = 0; // wave-uniform
+    auto wave_sync = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
-    if (top == BUILD_EVERYWHERE) {
-        emit(num_cells);
-    } else {
-        const rtg::SlotView view = views[i];
-        unsigned int (*stack)[BLOCK] = stack_all; // [depth][thread]: (level << 24) | cell
-        const int tx = threadIdx.x;
-        int sp = 0;
-        if (bits == BUILD_TOP_LEVEL) {
-            emit(top);
-        } else {
-            for (unsigned int k = 0; k < 4; k++)
-                stack[sp++][tx] = ((unsigned int)(BUILD_TOP_LEVEL + 1) << 24) | (top * 4 + k);
-        }
-        while (sp > 0) {
-            const unsigned int e = stack[--sp][tx];
-            const int level = (int)(e >> 24);
-            const unsigned int cell = e & 0xffffffu;
-            const rtg::CellCone cc = cells[rtg::level_offset(level) + cell];
-            if (!rtg::cell_meets_slot(cc, view)) continue;
-            if (level == bits) {
-                emit(cell);
-            } else {
-                for (unsigned int k = 0; k < 4; k++) stack[sp++][tx] = ((unsigned int)(level + 1) << 24) | (cell * 4 + k);
+    auto flush = [&]() {
+        if (!n_out) return;
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(cursor, (unsigned long long)n_out);
+        base = __shfl(base, 0, 64);
+        for (int k = lane; k < n_out; k += 64)
+            if (base + (unsigned long long)k < cap) {
+                keys[base + k] = okey[k];
+                vals[base + k] = oval[k];
             }
+        n_out = 0;
+    };
+
+    // this lane's slot: its view as 18 doubles (the first holds the two flags)
+    static_assert(sizeof(rtg::SlotView) == 144 && offsetof(rtg::SlotView, planes) == 4 && offsetof(rtg::SlotView, a) == 8 &&
+                      offsetof(rtg::SlotView, ct) == 32 && offsetof(rtg::SlotView, st) == 40 &&
+                      offsetof(rtg::SlotView, n) == 48 && offsetof(rtg::SlotView, b) == 120,
+                  "the view travels between lanes as 18 doubles");
+    double md[18];
+    for (int i = 0; i < 18; i++) md[i] = 0.0;
+    if (first + lane < num_slots) {
+        const double2 *vp = reinterpret_cast<const double2 *>(views + first + lane);
+        for (int i = 0; i < 9; i++) {
+            const double2 d = vp[i];
+            md[2 * i] = d.x;
+            md[2 * i + 1] = d.y;
         }
     }
-    if (!FILL) item_count[t] = n;
+    auto view_of = [](const double d[18]) {
+        rtg::SlotView v;
+        const unsigned long long f = (unsigned long long)__double_as_longlong(d[0]);
+        v.cone = (int)(unsigned int)f;
+        v.planes = ((f >> 32) & 0xffull) != 0;
+        for (int i = 0; i < 3; i++) v.a[i] = d[1 + i];
+        v.ct = d[4];
+        v.st = d[5];
+        for (int k = 0; k < 3; k++)
+            for (int i = 0; i < 3; i++) v.n[k][i] = d[6 + 3 * k + i];
+        for (int i = 0; i < 3; i++) v.b[i] = d[15 + i];
+        return v;
+    };
+    const rtg::SlotView mine = view_of(md);
+    {
+        const bool everywhere = mine.cone != 0 && rtg::slot_everywhere(mine);
+        const bool walk = mine.cone != 0 && !everywhere;
+        const unsigned long long me = __builtin_amdgcn_ballot_w64(everywhere);
+        if (everywhere) {
+            okey[lanes_below(me)] = num_cells;
+            oval[lanes_below(me)] = first + lane;
+        }
+        n_out = __popcll(me);
+        // roots: the four cells of level 1 (not tested themselves: the tables start at level 2)
+        const unsigned long long mw = __builtin_amdgcn_ballot_w64(walk);
+        if (walk)
+            for (unsigned int k = 0; k < 4; k++) stack[4 * lanes_below(mw) + k] = (unsigned int)lane | (1u << 6) | (k << 10);
+        sp = 4 * __popcll(mw);
+    }
+    wave_sync();
+    // the pieces this lane moves in each group of three loads: piece q = 64 t + lane of a sixteen-node round
+    int piece_node[3], piece_part[3];
+    for (int t = 0; t < 3; t++) {
+        const int q = 64 * t + lane;
+        piece_node[t] = q / 12;
+        piece_part[t] = q % 12;
+    }
+
+    while (sp > 0) {
+        int room = (GRID_LIST_STACK - GRID_LIST_RESERVE - sp) / 3;
+        if (room < 1) room = 1;
+        int take = sp < 64 ? sp : 64;
+        if (take > room) take = room;
+        sp -= take;
+        const bool has = lane < take;
+        const unsigned int node = has ? stack[sp + lane] : 0u;
+        const unsigned int item = node & 63u;
+        const int level = (int)((node >> 6) & 15u) + 1; // of the children
+        const unsigned int cell4 = (node >> 10) * 4u;
+        // the cones of the four children, for all 64 nodes: loads first, all in flight together
+        const unsigned int cone_at = has ? (unsigned int)rtg::level_offset(level) + cell4 : 0u;
+        auto load_piece = [&](int r, int t) {
+            const unsigned int src = (unsigned int)__shfl((int)cone_at, 16 * r + piece_node[t], 64);
+            return reinterpret_cast<const double2 *>(cells + src)[piece_part[t]];
+        };
+        const double2 pc0 = load_piece(0, 0), pc1 = load_piece(0, 1), pc2 = load_piece(0, 2);
+        const double2 pc3 = load_piece(1, 0), pc4 = load_piece(1, 1), pc5 = load_piece(1, 2);
+        const double2 pc6 = load_piece(2, 0), pc7 = load_piece(2, 1), pc8 = load_piece(2, 2);
+        const double2 pc9 = load_piece(3, 0), pc10 = load_piece(3, 1), pc11 = load_piece(3, 2);
+        // the view of the node's slot, from the lane that holds it
+        double vd[18];
+        for (int i = 0; i < 18; i++) vd[i] = __shfl(md[i], (int)item, 64);
+        const rtg::SlotView view = view_of(vd);
+        // ... and the cones to their nodes' lanes, sixteen nodes a round
+        double2 g0, g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11;
+        g0 = g1 = g2 = g3 = g4 = g5 = g6 = g7 = g8 = g9 = g10 = g11 = make_double2(0.0, 0.0);
+        const int put0 = piece_node[0] * GRID_LIST_STAGE_PITCH + piece_part[0];
+        const int put1 = piece_node[1] * GRID_LIST_STAGE_PITCH + piece_part[1];
+        const int put2 = piece_node[2] * GRID_LIST_STAGE_PITCH + piece_part[2];
+        const double2 *take_at = stage + (lane & 15) * GRID_LIST_STAGE_PITCH;
+#define RT_GRID_LIST_ROUND(R, A, B, C)                                                            \
+    stage[put0] = A; stage[put1] = B; stage[put2] = C;                                            \
+    wave_sync();                                                                                  \
+    if ((lane >> 4) == R) {                                                                       \
+        g0 = take_at[0]; g1 = take_at[1]; g2 = take_at[2]; g3 = take_at[3];                       \
+        g4 = take_at[4]; g5 = take_at[5]; g6 = take_at[6]; g7 = take_at[7];                       \
+        g8 = take_at[8]; g9 = take_at[9]; g10 = take_at[10]; g11 = take_at[11];                   \
+    }                                                                                             \
+    wave_sync();
+        RT_GRID_LIST_ROUND(0, pc0, pc1, pc2)
+        RT_GRID_LIST_ROUND(1, pc3, pc4, pc5)
+        RT_GRID_LIST_ROUND(2, pc6, pc7, pc8)
+        RT_GRID_LIST_ROUND(3, pc9, pc10, pc11)
+#undef RT_GRID_LIST_ROUND
+        const double2 got[12] = {g0, g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11};
+        bool pass[4] = {false, false, false, false};
+        if (has)
+            for (int k = 0; k < 4; k++) {
+                rtg::CellCone cc; // six doubles in three pieces
+                cc.a[0] = got[3 * k].x;
+                cc.a[1] = got[3 * k].y;
+                cc.a[2] = got[3 * k + 1].x;
+                cc.cpsi = got[3 * k + 1].y;
+                cc.spsi = got[3 * k + 2].x;
+                cc.psi = got[3 * k + 2].y;
+                pass[k] = rtg::cell_meets_slot(cc, view);
+            }
+        const bool leaf = level == bits;
+        for (int k = 0; k < 4; k++) {
+            const unsigned long long mp = __builtin_amdgcn_ballot_w64(pass[k] && !leaf);
+            const unsigned long long mo = __builtin_amdgcn_ballot_w64(pass[k] && leaf);
+            if (pass[k] && !leaf) stack[sp + lanes_below(mp)] = item | ((unsigned int)level << 6) | ((cell4 + (unsigned int)k) << 10);
+            if (pass[k] && leaf) {
+                okey[n_out + lanes_below(mo)] = cell4 + (unsigned int)k;
+                oval[n_out + lanes_below(mo)] = first + (int)item;
+            }
+            sp += __popcll(mp);
+            n_out += __popcll(mo);
+        }
+        if (sp > GRID_LIST_STACK - 4) { // cannot happen (see above)
+            if (lane == 0) *fault = 1;
+            break;
+        }
+        wave_sync();
+        if (n_out >= GRID_LIST_OUT) flush();
+    }
+    wave_sync();
+    flush();
 }
 
 // Step 3: off[c] = position of the first pair of cell c in the sorted keys (c = 0 .. num_cells + 1:

@@ -333,3 +333,31 @@ def test_torch_initialises_its_gpu_after_the_library_was_used():
         "print('ok')\n" % ROOT)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-1500:]
+
+
+@pytest.mark.parametrize("stage", ["intersect", "color"])
+def test_stage_that_fails_after_it_began_leaves_timers_and_context_usable(rt, oracle_mod, stage):
+    """A stage call that fails between its two timing events: rt_stage_ms still answers (the pair is
+    closed on the way out), the kernel log still reads, and the next frame is bit-equal to the oracle's."""
+    sc = small_scene("mixed")
+    g, c = rt.RayTracer(96, 64), oracle_mod.Oracle(96, 64, threads=8)
+    with g:
+        for o in (g, c):
+            setup(o, sc, 2)
+        g.render(2)
+        assert all(m > 0 for m in g.stage_ms())
+        g.kernel_log()
+        g.raygen()
+        if stage == "color":
+            g.intersect()
+        g.set_option("fail_next_stage", 1)
+        with pytest.raises(rt.RtError) as e:
+            getattr(g, stage)()
+        assert e.value.code == -2 and "RT_OPT_FAIL_NEXT_STAGE" in str(e.value)
+        ms = g.stage_ms()                     # does not raise; the failed call's pair is closed
+        assert all(np.isfinite(m) and m >= 0 for m in ms) and ms[0] > 0
+        g.kernel_log()
+        getattr(g, stage)()                   # the option is back to 0
+        g.render(2); c.render(2)
+        same("after a failed stage call", g, c)
+        assert all(m > 0 for m in g.stage_ms())
