@@ -155,6 +155,9 @@ struct rt_ctx {
     int *sort_slots = nullptr;
     // ... by counting: rays per key, their exclusive scan, rocprim's temporary storage for the scan
     unsigned int *bin_hist_d = nullptr, *bin_off_d = nullptr;
+    size_t bin_hist_bytes = 0;
+    bool bin_hist_dirty = true;      // not known to be all zero
+    bool count_clean[2] = {false, false}; // count_d[0] / [1] (rt_intersect's / rt_color's list length) is zero
     void *bin_temp_d = nullptr;
     size_t bin_temp_bytes = 0;
     int *count_d = nullptr; // [0] intersect list, [1] shade list, [2],[3] alist sizes
@@ -371,6 +374,7 @@ extern "C" int rt_create(rt_ctx **out, int hip_device, int width, int height)
         // keys are direction cells of at most MAX_BITS bits per axis (plus one bin for the scan's total)
         const size_t bins = ((size_t)1 << (2 * rtg::MAX_BITS)) + 1;
         CRCHK(hipMalloc(&c->bin_hist_d, bins * sizeof(unsigned int)));
+        c->bin_hist_bytes = bins * sizeof(unsigned int);
         CRCHK(hipMalloc(&c->bin_off_d, bins * sizeof(unsigned int)));
         CRCHK(rocprim::exclusive_scan(nullptr, c->bin_temp_bytes, c->bin_hist_d, c->bin_off_d, 0u, bins,
                                       rocprim::plus<unsigned int>()));
@@ -1030,7 +1034,10 @@ static int launch_traverse(rt_ctx *c, TraverseParams p, int n_upper, int n_slot,
 static int bin_slots(rt_ctx *c, const unsigned int *keys, const int *count, int n_upper, int key_bits, int *out)
 {
     const size_t bins = ((size_t)1 << key_bits) + 1;
-    HIPCHK(c, hipMemsetAsync(c->bin_hist_d, 0, bins * sizeof(unsigned int), c->stream));
+    // the scatter counts the histogram back down to zero: it only needs clearing when a call before this
+    // one did not get as far as its scatter
+    if (c->bin_hist_dirty) HIPCHK(c, hipMemsetAsync(c->bin_hist_d, 0, c->bin_hist_bytes, c->stream));
+    c->bin_hist_dirty = true;
     const dim3 grid(list_blocks(n_upper, BLOCK));
     hipLaunchKernelGGL(bin_count_kernel, grid, dim3(BLOCK), 0, c->stream, keys, count, c->bin_hist_d);
     HIPCHK(c, hipGetLastError());
@@ -1040,6 +1047,7 @@ static int bin_slots(rt_ctx *c, const unsigned int *keys, const int *count, int 
     hipLaunchKernelGGL(bin_scatter_kernel, grid, dim3(BLOCK), 0, c->stream, keys, count,
                        (const unsigned int *)c->bin_off_d, c->bin_hist_d, out);
     HIPCHK(c, hipGetLastError());
+    c->bin_hist_dirty = false;
     return RT_OK;
 }
 
@@ -1119,7 +1127,7 @@ static int launch_traverse_clustered(rt_ctx *c, TraverseParams p, int n_upper, i
         p.walk_t = c->walk_t_d;
         p.walk_count = c->walk_count_d;
         p.walk_budget = c->walk_budget;
-        HIPCHK(c, hipMemsetAsync(c->walk_count_d, 0, sizeof(int), st));
+        // (walk_count_d was zeroed by this stage call's intersect_setup_kernel)
         hipLaunchKernelGGL(traverse_voxel_kernel, dim3(cdiv(n_upper, BLOCK)), dim3(BLOCK), 0, st, p);
         HIPCHK(c, hipGetLastError());
         if (!fork) {
@@ -1373,7 +1381,9 @@ extern "C" int rt_intersect(rt_ctx *c)
             if (int r = refresh_camera_recs(c)) return r;
             list = c->perm_d;
         } else {
-            HIPCHK(c, hipMemsetAsync(c->count_d, 0, sizeof(int), c->stream));
+            // (zero already when the last stage call to finish was an rt_color, whose last kernel saw to it)
+            if (!c->count_clean[0]) HIPCHK(c, hipMemsetAsync(c->count_d, 0, sizeof(int), c->stream));
+            c->count_clean[0] = false;
             hipLaunchKernelGGL((compact_kernel<0>), dim3(list_blocks(c->n_rays, BLOCK * COMPACT_ITERS)), dim3(BLOCK), 0,
                                c->stream, c->rays, (const int *)c->perm_d, (const int *)nullptr, (const int *)nullptr,
                                c->n_rays, (const int *)nullptr, c->list, c->count_d, (uint32_t *)nullptr);
@@ -1391,7 +1401,7 @@ extern "C" int rt_intersect(rt_ctx *c)
         hipLaunchKernelGGL(intersect_setup_kernel, dim3(list_blocks(n_upper, BLOCK)), dim3(BLOCK), 0, c->stream, c->rays,
                            list, count, n_upper, c->job, c->scratch.best, shared ? 1 : (clustered ? 2 : 0),
                            shared_origin(c, c->cam.pos, 1.0f), sorted ? c->sort_keys : (unsigned int *)nullptr,
-                           n_slot >= 0 ? c->klog_n_d + n_slot : (int *)nullptr);
+                           n_slot >= 0 ? c->klog_n_d + n_slot : (int *)nullptr, c->walk_count_d);
         HIPCHK(c, hipGetLastError());
         c->forked = false;
         if (clustered && c->band_entries && sweeps_side_by_side(c)) {
@@ -1427,8 +1437,9 @@ extern "C" int rt_intersect(rt_ctx *c)
         }
         hipLaunchKernelGGL(intersect_finish_kernel, dim3(list_blocks(n_upper, BLOCK)), dim3(BLOCK), 0, c->stream,
                            c->rays, list, count, n_upper, c->job, c->scratch.best, c->verts, c->num_tris, c->cam,
-                           c->depth, c->counters_d);
+                           c->depth, c->counters_d, c->count_d + 1);
         HIPCHK(c, hipGetLastError());
+        c->count_clean[1] = true;
     }
     c->hits_follow_pixels = c->rays_share_camera_origin;
     c->rays_share_camera_origin = false;
@@ -1463,7 +1474,9 @@ extern "C" int rt_color(rt_ctx *c)
             HIPCHK(c, hipGetLastError());
         } else {
             if (int r = refresh_light_recs(c)) return r;
-            HIPCHK(c, hipMemsetAsync(c->count_d + 1, 0, sizeof(int), c->stream));
+            // (zero already when the last stage call to finish was an rt_intersect, whose last kernel saw to it)
+            if (!c->count_clean[1]) HIPCHK(c, hipMemsetAsync(c->count_d + 1, 0, sizeof(int), c->stream));
+            c->count_clean[1] = false;
             hipLaunchKernelGGL((compact_kernel<1>), dim3(list_blocks(c->n_rays, BLOCK * COMPACT_ITERS)), dim3(BLOCK), 0,
                                c->stream, c->rays, (const int *)c->perm_d, (const int *)nullptr, (const int *)nullptr,
                                c->n_rays, (const int *)nullptr, c->list, c->count_d + 1, c->fb);
@@ -1542,8 +1555,9 @@ extern "C" int rt_color(rt_ctx *c)
             }
             hipLaunchKernelGGL(color_finish_kernel, g0, dim3(BLOCK), 0, c->stream, c->rays, (const int *)c->list, cnt0,
                                c->scratch, c->verts, c->num_vertices, (const uint32_t *)c->tex, c->tex_w, c->tex_h,
-                               c->fb);
+                               c->fb, c->count_d);
             HIPCHK(c, hipGetLastError());
+            c->count_clean[0] = true;
         }
     }
     // a killed ray keeps its shifted origin: the rays no longer share an origin

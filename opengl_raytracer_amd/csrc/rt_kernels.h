@@ -390,10 +390,14 @@ __device__ __forceinline__ v3 vpos(const rt_vertex *__restrict__ v, int i)
 __global__ __launch_bounds__(BLOCK) void intersect_setup_kernel(RaySoA r, const int *__restrict__ list,
                                                                 const int *__restrict__ count, int n_fixed, Job job,
                                                                 unsigned long long *__restrict__ best, int shared,
-                                                                SharedOrigin so, unsigned int *keys, int *n_out)
+                                                                SharedOrigin so, unsigned int *keys, int *n_out,
+                                                                int *zero_this)
 {
     const int n = count ? *count : n_fixed;
     if (n_out && blockIdx.x == 0 && threadIdx.x == 0) *n_out = n; // for the kernel log
+    // a counter that a later kernel of this stage call counts up from zero, and no kernel of this
+    // launch or before it still reads (here: the number of walks handed over)
+    if (zero_this && blockIdx.x == 0 && threadIdx.x == 0) *zero_this = 0;
     RT_FOR_EACH_SLOT(slot, n) {
     const int i = list ? list[slot] : slot;
     v3 o = rtx::V(r.ox[i], r.oy[i], r.oz[i]);
@@ -418,7 +422,32 @@ __global__ __launch_bounds__(BLOCK) void intersect_setup_kernel(RaySoA r, const 
 // again after the scatter.
 // ---------------------------------------------------------------------------
 // (Rays of a wavefront often share a key -- neighbouring pixels, one cell -- and atomics on one address are
-// served one after the other: a wavefront issues one atomic per distinct key, on behalf of all its lanes.)
+// served one after the other: a wavefront issues one atomic per distinct key, on behalf of all its lanes.
+// The lanes are first grouped by key with ballots alone; then all the groups' leaders issue their atomics
+// in ONE instruction, so a wavefront waits for one round trip, not one per key.)
+struct KeyGroup {
+    int leader;        // the lowest lane with this lane's key
+    unsigned int rank; // lanes with this key below this one
+    unsigned int size; // lanes with this key
+};
+__device__ __forceinline__ KeyGroup group_by_key(unsigned int key, bool valid, int lane)
+{
+    KeyGroup g{lane, 0u, 1u};
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(valid);
+    while (todo) {
+        const int leader = __builtin_ctzll(todo);
+        const unsigned int k0 = (unsigned int)__builtin_amdgcn_readlane((int)key, leader);
+        const unsigned long long same = __builtin_amdgcn_ballot_w64(valid && key == k0);
+        if (valid && key == k0) {
+            g.leader = leader;
+            g.rank = (unsigned int)lanes_below(same);
+            g.size = (unsigned int)__popcll(same);
+        }
+        todo &= ~same;
+    }
+    return g;
+}
+
 __global__ __launch_bounds__(BLOCK) void bin_count_kernel(const unsigned int *__restrict__ keys,
                                                           const int *__restrict__ count, unsigned int *__restrict__ hist)
 {
@@ -428,14 +457,8 @@ __global__ __launch_bounds__(BLOCK) void bin_count_kernel(const unsigned int *__
         const int slot = base + threadIdx.x;
         const bool valid = slot < n;
         const unsigned int key = valid ? keys[slot] : 0xffffffffu;
-        unsigned long long todo = __builtin_amdgcn_ballot_w64(valid);
-        while (todo) {
-            const int leader = __builtin_ctzll(todo);
-            const unsigned int k0 = (unsigned int)__builtin_amdgcn_readlane((int)key, leader);
-            const unsigned long long same = __builtin_amdgcn_ballot_w64(key == k0) & todo;
-            if (lane == leader) atomicAdd(&hist[k0], (unsigned int)__popcll(same));
-            todo &= ~same;
-        }
+        const KeyGroup g = group_by_key(key, valid, lane);
+        if (valid && g.leader == lane) atomicAdd(&hist[key], g.size);
     }
 }
 
@@ -450,17 +473,11 @@ __global__ __launch_bounds__(BLOCK) void bin_scatter_kernel(const unsigned int *
         const int slot = base + threadIdx.x;
         const bool valid = slot < n;
         const unsigned int key = valid ? keys[slot] : 0xffffffffu;
-        unsigned long long todo = __builtin_amdgcn_ballot_w64(valid);
-        while (todo) {
-            const int leader = __builtin_ctzll(todo);
-            const unsigned int k0 = (unsigned int)__builtin_amdgcn_readlane((int)key, leader);
-            const unsigned long long same = __builtin_amdgcn_ballot_w64(key == k0) & todo;
-            unsigned int first = 0;
-            if (lane == leader) first = atomicSub(&hist[k0], (unsigned int)__popcll(same)) - (unsigned int)__popcll(same);
-            first = (unsigned int)__builtin_amdgcn_readlane((int)first, leader);
-            if (key == k0 && valid) out[off[k0] + first + (unsigned int)lanes_below(same)] = slot;
-            todo &= ~same;
-        }
+        const KeyGroup g = group_by_key(key, valid, lane);
+        unsigned int first = 0;
+        if (valid && g.leader == lane) first = atomicSub(&hist[key], g.size) - g.size;
+        first = (unsigned int)__shfl((int)first, g.leader, 64);
+        if (valid) out[off[key] + first + g.rank] = slot;
     }
 }
 
@@ -2304,10 +2321,12 @@ __global__ __launch_bounds__(BLOCK) void intersect_finish_kernel(RaySoA r, const
                                                                  const unsigned long long *__restrict__ best,
                                                                  const rt_vertex *__restrict__ verts, int num_tris,
                                                                  Camera cam, float *__restrict__ depth,
-                                                                 unsigned long long *counters)
+                                                                 unsigned long long *counters, int *zero_this)
 {
     const int n = count ? *count : n_fixed;
     if (blockIdx.x == 0 && threadIdx.x == 0) add_counter(counters, C_CH_RAYS, (unsigned long long)n);
+    // the list counter of the OTHER stage, which no kernel of this stage call reads: zero for its next use
+    if (zero_this && blockIdx.x == 0 && threadIdx.x == 0) *zero_this = 0;
     RT_FOR_EACH_SLOT(slot, n) {
     const int i = list ? list[slot] : slot;
     const v3 o = rtx::V(job.ox[slot], job.oy[slot], job.oz[slot]);
@@ -2454,9 +2473,11 @@ __global__ __launch_bounds__(BLOCK) void color_finish_kernel(RaySoA r, const int
                                                              const int *__restrict__ count, Scratch s,
                                                              const rt_vertex *__restrict__ verts, int num_vertices,
                                                              const uint32_t *__restrict__ tex, int tex_w, int tex_h,
-                                                             uint32_t *__restrict__ fb)
+                                                             uint32_t *__restrict__ fb, int *zero_this)
 {
     const int n = *count;
+    // the list counter of the OTHER stage, which no kernel of this stage call reads: zero for its next use
+    if (zero_this && blockIdx.x == 0 && threadIdx.x == 0) *zero_this = 0;
     RT_FOR_EACH_SLOT(slot, n) {
     const int i = list0[slot];
     v3 fin = rtx::V(0.1f, 0.1f, 0.1f);

@@ -24,6 +24,14 @@ def share(tile_rows, rank, world):
     return (time.perf_counter() - t0) / 2 * 1e3
 
 
+if os.environ.get("ONLY_RANK"):
+    # one rank's share, several frames (for a profiler run around this program)
+    tr = int(os.environ.get("TILE_ROWS", "15").split(",")[0])
+    for _ in range(3):
+        print("share of rank %s: %.3f ms" % (os.environ["ONLY_RANK"], share(tr, int(os.environ["ONLY_RANK"]), world)), flush=True)
+    print([round(x, 3) for x in g.stage_ms()])
+    g.close()
+    sys.exit(0)
 base = share(wl["height"], 0, 1)
 print("whole frame %.2f ms" % base, flush=True)
 for tr in [int(x) for x in os.environ.get("TILE_ROWS", "16,32,64,128").split(",")]:
