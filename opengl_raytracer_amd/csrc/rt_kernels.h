@@ -1955,14 +1955,97 @@ __global__ __launch_bounds__(BLOCK) void traverse_bandcell_kernel(TraverseParams
     const unsigned int every = 1u << (2 * p.grid_bits);
     const unsigned int eoff = p.band_off[every];
     const int ecnt = (int)(p.band_off[every + 1] - eoff);
-    while (remaining) {
-        const int leader = __builtin_ctzll(remaining);
-        const unsigned int c0 = (unsigned int)__builtin_amdgcn_readlane((int)cell, leader);
-        const unsigned long long group = __builtin_amdgcn_ballot_w64(cell == c0) & remaining;
-        remaining &= ~group;
-        const unsigned int off = p.band_off[c0];
-        const int cnt = (int)(p.band_off[c0 + 1] - off);
-        sweep(p.band_entries + off, cnt, p.band_entries + eoff, ecnt, group);
+    // The rays of the wavefront, cell by cell, each cell's list 64 members a step.  A step is two loads
+    // one after the other (the member's position on the list, then its record), and a wavefront whose rays
+    // sit in cells of their own makes hundreds of steps: the steps are laid out beforehand (where each
+    // cell's list starts is read up front, one cell per lane) and their loads run ahead -- positions two
+    // steps, records one step before the step that tests them.
+    unsigned int my_off = 0;
+    int my_cnt = 0;
+    if (valid && !wild) {
+        my_off = p.band_off[cell];
+        my_cnt = (int)(p.band_off[cell + 1] - my_off);
+    }
+    struct Step { // wave-uniform
+        unsigned long long group; // the rays of the step's cell; 0: past the last step
+        unsigned int off;
+        int cnt, base;
+    };
+    auto advance = [&](Step st) {
+        st.base += 64;
+        while (!st.group || st.base >= st.cnt + ecnt) {
+            if (!remaining) {
+                st.group = 0;
+                return st;
+            }
+            const int leader = __builtin_ctzll(remaining);
+            const unsigned int c0 = (unsigned int)__builtin_amdgcn_readlane((int)cell, leader);
+            st.group = __builtin_amdgcn_ballot_w64(cell == c0) & remaining;
+            remaining &= ~st.group;
+            st.off = (unsigned int)__builtin_amdgcn_readlane((int)my_off, leader);
+            st.cnt = __builtin_amdgcn_readlane(my_cnt, leader);
+            st.base = 0;
+        }
+        return st;
+    };
+    auto load_pos = [&](const Step &st) {
+        const int idx = st.base + lane;
+        if (!st.group || idx >= st.cnt + ecnt) return -1;
+        return idx < st.cnt ? p.band_entries[st.off + idx] : p.band_entries[eoff + idx - st.cnt];
+    };
+    struct Recs {
+        float4 m1, m2;
+    };
+    auto load_recs = [&](int pos) {
+        Recs r{make_float4(0.0f, 0.0f, 0.0f, 2.0f), make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1))};
+        if (pos >= 0) {
+            r.m1 = p.nrecs[2 * pos];
+            r.m2 = p.nrecs[2 * pos + 1];
+        }
+        return r;
+    };
+    auto test_step = [&](const Step &st, const Recs &rc) {
+        const float4 m1 = rc.m1, m2 = rc.m2;
+        const int tri = __float_as_int(m2.w);
+        const bool member = tri >= 0 && m1.w != 2.0f; // not padding, not "never accepted"
+        unsigned long long m = st.group;
+        while (m) {
+            const int r = __builtin_ctzll(m);
+            m &= m - 1;
+            const float rbx = readlane_f(bx, r), rby = readlane_f(by, r), rbz = readlane_f(bz, r);
+            const float rox = readlane_f(ox, r), roy = readlane_f(oy, r), roz = readlane_f(oz, r);
+            const float t0 = fmaf(m1.z, rbz, fmaf(m1.y, rby, m1.x * rbx));
+            const float h0 = fmaf(m2.z, roz, fmaf(m2.y, roy, fmaf(m2.x, rox, -m1.w)));
+            const bool in = member && fmaxf(fabsf(t0), fabsf(h0)) < 1.0f;
+            const unsigned long long h = __builtin_amdgcn_ballot_w64(in);
+            if (h) {
+                if (in) queue[qcount + lanes_below(h)] = ((unsigned int)tri << 6) | (unsigned int)r;
+                qcount += __popcll(h);
+                if (qcount > GRID_QCAP - 64) drain(false);
+            }
+        }
+        n_slow += __popcll(st.group);
+    };
+    {
+        Step sa = advance(Step{0ull, 0u, 0, 0}); // the step whose positions are being read
+        int pos_a = load_pos(sa);
+        Step sb = sa;                            // the step whose records are being read
+        Recs rec_b = load_recs(pos_a);
+        if (sa.group) {
+            sa = advance(sa);
+            pos_a = load_pos(sa);
+        }
+        while (sb.group) {
+            const Step sc = sb;
+            const Recs rec_c = rec_b;
+            sb = sa;
+            rec_b = load_recs(pos_a);
+            if (sa.group) {
+                sa = advance(sa);
+                pos_a = load_pos(sa);
+            }
+            test_step(sc, rec_c);
+        }
     }
     const unsigned long long wilds = __builtin_amdgcn_ballot_w64(wild);
     if (wilds) sweep(nullptr, p.num_ngroups * NGROUP, nullptr, 0, wilds);
