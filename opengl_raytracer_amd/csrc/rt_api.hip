@@ -1030,17 +1030,21 @@ static int launch_traverse(rt_ctx *c, TraverseParams p, int n_upper, int n_slot,
     return klog_end(c, ks);
 }
 
-// out = the slots 0 .. *count - 1 grouped by key (any order inside a key): count, scan, scatter.
-static int bin_slots(rt_ctx *c, const unsigned int *keys, const int *count, int n_upper, int key_bits, int *out)
+// Rays grouped by key (any order inside a key): the kernel that forms the keys counts them into the
+// histogram (bin_begin before its launch), then scan and scatter (bin_finish): out = the slots
+// 0 .. *count - 1 in key order.
+static int bin_begin(rt_ctx *c)
 {
-    const size_t bins = ((size_t)1 << key_bits) + 1;
     // the scatter counts the histogram back down to zero: it only needs clearing when a call before this
     // one did not get as far as its scatter
     if (c->bin_hist_dirty) HIPCHK(c, hipMemsetAsync(c->bin_hist_d, 0, c->bin_hist_bytes, c->stream));
     c->bin_hist_dirty = true;
+    return RT_OK;
+}
+static int bin_finish(rt_ctx *c, const unsigned int *keys, const int *count, int n_upper, int key_bits, int *out)
+{
+    const size_t bins = ((size_t)1 << key_bits) + 1;
     const dim3 grid(list_blocks(n_upper, BLOCK));
-    hipLaunchKernelGGL(bin_count_kernel, grid, dim3(BLOCK), 0, c->stream, keys, count, c->bin_hist_d);
-    HIPCHK(c, hipGetLastError());
     size_t bytes = c->bin_temp_bytes;
     HIPCHK(c, rocprim::exclusive_scan(c->bin_temp_d, bytes, c->bin_hist_d, c->bin_off_d, 0u, bins,
                                       rocprim::plus<unsigned int>(), c->stream));
@@ -1127,7 +1131,7 @@ static int launch_traverse_clustered(rt_ctx *c, TraverseParams p, int n_upper, i
         p.walk_t = c->walk_t_d;
         p.walk_count = c->walk_count_d;
         p.walk_budget = c->walk_budget;
-        // (walk_count_d was zeroed by this stage call's intersect_setup_kernel)
+        // (walk_count_d was zeroed by the kernel of this stage call that prepared the slots)
         hipLaunchKernelGGL(traverse_voxel_kernel, dim3(cdiv(n_upper, BLOCK)), dim3(BLOCK), 0, st, p);
         HIPCHK(c, hipGetLastError());
         if (!fork) {
@@ -1376,40 +1380,51 @@ extern "C" int rt_intersect(rt_ctx *c)
         const int *list = nullptr, *count = nullptr;
         const int n_upper = c->n_rays; // the live rays are counted on the device; the host does not wait for it
         int n_slot = -1;
-        if (shared) {
-            // fresh rays: all live, all through camera_pos; visited in pixel-tile order
-            if (int r = refresh_camera_recs(c)) return r;
-            list = c->perm_d;
-        } else {
-            // (zero already when the last stage call to finish was an rt_color, whose last kernel saw to it)
-            if (!c->count_clean[0]) HIPCHK(c, hipMemsetAsync(c->count_d, 0, sizeof(int), c->stream));
-            c->count_clean[0] = false;
-            hipLaunchKernelGGL((compact_kernel<0>), dim3(list_blocks(c->n_rays, BLOCK * COMPACT_ITERS)), dim3(BLOCK), 0,
-                               c->stream, c->rays, (const int *)c->perm_d, (const int *)nullptr, (const int *)nullptr,
-                               c->n_rays, (const int *)nullptr, c->list, c->count_d, (uint32_t *)nullptr);
-            HIPCHK(c, hipGetLastError());
-            list = c->list;
-            count = c->count_d;
-            n_slot = next_n_slot(c);
-        }
         // a few hundred triangles are streamed through the per-pair filter faster than their groups
         // are swept
         // (the group sweeps queue pairs as triangle * 2048 + ray in 32 bits: larger meshes take it too)
         const bool clustered = !shared && c->trace_mode == RT_TRACE_CLUSTERED &&
                                c->num_tris >= c->cluster_min_tris && c->num_tris < (1 << 21);
         const bool sorted = clustered && n_upper >= c->sort_min_rays && c->num_ngroups >= 64;
-        hipLaunchKernelGGL(intersect_setup_kernel, dim3(list_blocks(n_upper, BLOCK)), dim3(BLOCK), 0, c->stream, c->rays,
-                           list, count, n_upper, c->job, c->scratch.best, shared ? 1 : (clustered ? 2 : 0),
-                           shared_origin(c, c->cam.pos, 1.0f), sorted ? c->sort_keys : (unsigned int *)nullptr,
-                           n_slot >= 0 ? c->klog_n_d + n_slot : (int *)nullptr, c->walk_count_d);
-        HIPCHK(c, hipGetLastError());
+        if (shared) {
+            // fresh rays: all live, all through camera_pos; visited in pixel-tile order
+            if (int r = refresh_camera_recs(c)) return r;
+            list = c->perm_d;
+            hipLaunchKernelGGL(intersect_setup_kernel, dim3(list_blocks(n_upper, BLOCK)), dim3(BLOCK), 0, c->stream,
+                               c->rays, list, count, n_upper, c->job, c->scratch.best, 1,
+                               shared_origin(c, c->cam.pos, 1.0f), (unsigned int *)nullptr, (unsigned int *)nullptr,
+                               (int *)nullptr, c->walk_count_d);
+            HIPCHK(c, hipGetLastError());
+        } else {
+            // (zero already when the last stage call to finish was an rt_color, whose last kernel saw to it)
+            if (!c->count_clean[0]) HIPCHK(c, hipMemsetAsync(c->count_d, 0, sizeof(int), c->stream));
+            c->count_clean[0] = false;
+            if (sorted)
+                if (int r = bin_begin(c)) return r;
+            // the live rays are filed under slots, and each slot is prepared by the thread that files it
+            CompactWork work{};
+            work.job = c->job;
+            work.best = c->scratch.best;
+            work.shared = clustered ? 2 : 0;
+            work.so = shared_origin(c, c->cam.pos, 1.0f);
+            work.keys = sorted ? c->sort_keys : nullptr;
+            work.hist = sorted ? c->bin_hist_d : nullptr;
+            work.zero_this = c->walk_count_d;
+            hipLaunchKernelGGL((compact_kernel<0>), dim3(list_blocks(c->n_rays, BLOCK * COMPACT_ITERS)), dim3(BLOCK), 0,
+                               c->stream, c->rays, (const int *)c->perm_d, (const int *)nullptr, (const int *)nullptr,
+                               c->n_rays, (const int *)nullptr, c->list, c->count_d, (uint32_t *)nullptr, work);
+            HIPCHK(c, hipGetLastError());
+            list = c->list;
+            count = c->count_d;
+            n_slot = next_n_slot(c);
+        }
         c->forked = false;
         if (clustered && c->band_entries && sweeps_side_by_side(c)) {
             if (int r = fork_side_stream(c, n_slot, &c->forked_ks)) return r;
             c->forked = true;
         }
         if (sorted)
-            if (int r = bin_slots(c, c->sort_keys, count, n_upper, sort_key_bits(c), c->sort_slots)) return r;
+            if (int r = bin_finish(c, c->sort_keys, count, n_upper, sort_key_bits(c), c->sort_slots)) return r;
         TraverseParams p{};
         fill_traverse_common(c, p);
         p.alist = nullptr;
@@ -1437,7 +1452,8 @@ extern "C" int rt_intersect(rt_ctx *c)
         }
         hipLaunchKernelGGL(intersect_finish_kernel, dim3(list_blocks(n_upper, BLOCK)), dim3(BLOCK), 0, c->stream,
                            c->rays, list, count, n_upper, c->job, c->scratch.best, c->verts, c->num_tris, c->cam,
-                           c->depth, c->counters_d, c->count_d + 1);
+                           c->depth, c->counters_d, c->count_d + 1,
+                           n_slot >= 0 ? c->klog_n_d + n_slot : (int *)nullptr);
         HIPCHK(c, hipGetLastError());
         c->count_clean[1] = true;
     }
@@ -1477,16 +1493,17 @@ extern "C" int rt_color(rt_ctx *c)
             // (zero already when the last stage call to finish was an rt_intersect, whose last kernel saw to it)
             if (!c->count_clean[1]) HIPCHK(c, hipMemsetAsync(c->count_d + 1, 0, sizeof(int), c->stream));
             c->count_clean[1] = false;
+            // the rays with a finite origin are filed under slots (and counted on the device; the host does not
+            // wait for it), each slot prepared for the loop over the lights by the thread that files it
+            CompactWork work{};
+            work.scratch = c->scratch;
             hipLaunchKernelGGL((compact_kernel<1>), dim3(list_blocks(c->n_rays, BLOCK * COMPACT_ITERS)), dim3(BLOCK), 0,
                                c->stream, c->rays, (const int *)c->perm_d, (const int *)nullptr, (const int *)nullptr,
-                               c->n_rays, (const int *)nullptr, c->list, c->count_d + 1, c->fb);
+                               c->n_rays, (const int *)nullptr, c->list, c->count_d + 1, c->fb, work);
             HIPCHK(c, hipGetLastError());
-            // the rays with a finite origin are counted on the device; the host does not wait for it
             const int n0 = c->n_rays;
             const int *cnt0 = c->count_d + 1;
             const dim3 g0(list_blocks(n0, BLOCK));
-            hipLaunchKernelGGL(color_begin_kernel, g0, dim3(BLOCK), 0, c->stream, c->rays, c->list, cnt0, c->scratch);
-            HIPCHK(c, hipGetLastError());
             const bool exact = c->trace_mode == RT_TRACE_EXACT;
             const int n_trav = exact ? c->num_tris : c->num_slots; // slots, or triangles in the all-pairs mode
             const int chunk = shadow_chunk_tris(n_trav);
@@ -1496,14 +1513,17 @@ extern "C" int rt_color(rt_ctx *c)
                 const bool sorted = c->trace_mode == RT_TRACE_CLUSTERED && n0 >= c->sort_min_rays &&
                                     c->num_slots >= 8192 && !(use_grid(c) && c->hits_follow_pixels);
                 const int n_slot = next_n_slot(c);
+                if (sorted)
+                    if (int r = bin_begin(c)) return r;
                 hipLaunchKernelGGL(shadow_setup_kernel, g0, dim3(BLOCK), 0, c->stream, cnt0, c->scratch, c->job,
                                    c->lights[a].pos[0], c->lights[a].pos[1], c->lights[a].pos[2],
                                    shared_origin(c, c->lights[a].pos, -1.0f), c->counters_d,
-                                   sorted ? c->sort_keys : (unsigned int *)nullptr, c->klog_n_d + n_slot);
+                                   sorted ? c->sort_keys : (unsigned int *)nullptr,
+                                   sorted ? c->bin_hist_d : (unsigned int *)nullptr, c->klog_n_d + n_slot);
                 HIPCHK(c, hipGetLastError());
                 const int *alist = nullptr; // nullptr: slots 0..n-1
                 if (sorted) {
-                    if (int r = bin_slots(c, c->sort_keys, cnt0, n0, sort_key_bits(c), c->sort_slots)) return r;
+                    if (int r = bin_finish(c, c->sort_keys, cnt0, n0, sort_key_bits(c), c->sort_slots)) return r;
                     alist = c->sort_slots;
                 }
                 const int *acount = cnt0;
@@ -1542,7 +1562,8 @@ extern "C" int rt_color(rt_ctx *c)
                         HIPCHK(c, hipMemsetAsync(ocount, 0, sizeof(int), c->stream));
                         hipLaunchKernelGGL((compact_kernel<2>), dim3(list_blocks(n0, BLOCK * COMPACT_ITERS)),
                                            dim3(BLOCK), 0, c->stream, c->rays, (const int *)nullptr, alist, acount, n0,
-                                           (const int *)c->scratch.occ, c->alist[pp], ocount, (uint32_t *)nullptr);
+                                           (const int *)c->scratch.occ, c->alist[pp], ocount, (uint32_t *)nullptr,
+                                           CompactWork{});
                         HIPCHK(c, hipGetLastError());
                         alist = c->alist[pp];
                         acount = ocount;

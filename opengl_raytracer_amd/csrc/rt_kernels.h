@@ -205,85 +205,6 @@ __global__ __launch_bounds__(BLOCK) void cluster_cone_kernel(const rtf::ConeRec 
     out[c] = r;
 }
 
-// ---------------------------------------------------------------------------
-// stream compaction: out[] = the entries that satisfy a predicate; workgroup
-// segments land in arbitrary order, entries keep their order inside a segment of
-// 2048.
-// Rays are visited through `perm`, the enumeration of the frame's pixels in 8x8 tiles
-// (Morton order inside 32x32 blocks), so that 64 consecutive list entries are rays through
-// neighbouring pixels: a wavefront's rays then see the same few triangles.
-//   MODE 0: ray indices i in [0,n) that are live      (primitiveID != -2)   -- before intersect
-//   MODE 1: ray indices with a finite origin                               -- before shading;
-//           the others are reference-grey (see color_finish_kernel) and get their pixel here
-//   MODE 2: slots of in_list (or 0..n-1 when in_list is null) whose shadow ray is not yet
-//           occluded (occ[slot] == 0)                                      -- between shadow chunks
-// ---------------------------------------------------------------------------
-constexpr int COMPACT_ITERS = 8;
-
-template <int MODE>
-__global__ __launch_bounds__(BLOCK) void compact_kernel(RaySoA r, const int *__restrict__ perm,
-                                                        const int *__restrict__ in_list,
-                                                        const int *__restrict__ in_count, int n_fixed,
-                                                        const int *__restrict__ occ, int *__restrict__ out,
-                                                        int *__restrict__ out_count, uint32_t *__restrict__ fb)
-{
-    __shared__ int s_cnt[COMPACT_ITERS][BLOCK / 64];
-    __shared__ int s_base;
-    const int n = in_count ? *in_count : n_fixed;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // the launch has a fixed number of workgroups; each takes every gridDim.x-th chunk
-    for (int chunk = blockIdx.x * (BLOCK * COMPACT_ITERS); chunk < n; chunk += (int)gridDim.x * (BLOCK * COMPACT_ITERS)) {
-    unsigned long long masks[COMPACT_ITERS];
-    int value[COMPACT_ITERS];
-#pragma unroll
-    for (int it = 0; it < COMPACT_ITERS; it++) {
-        const int i = chunk + it * BLOCK + tid;
-        bool p = false;
-        value[it] = i;
-        if (i < n) {
-            if (MODE == 0) {
-                const int ri = perm[i]; // rays are visited in pixel-tile order
-                value[it] = ri;
-                p = r.id[ri] != -2;
-            } else if (MODE == 1) {
-                const int ri = perm[i];
-                value[it] = ri;
-                float a = r.ox[ri], b = r.oy[ri], c = r.oz[ri];
-                // finite <=> |x| < inf (false for NaN)
-                p = (fabsf(a) < INFINITY) && (fabsf(b) < INFINITY) && (fabsf(c) < INFINITY);
-                if (!p) fb[ri] = 0xff1a1a1au; // vec3(0.1) -> 26, alpha 255
-            } else {
-                const int slot = in_list ? in_list[i] : i;
-                value[it] = slot;
-                p = occ[slot] == 0;
-            }
-        }
-        masks[it] = __ballot(p);
-        if (lane == 0) s_cnt[it][wave] = __popcll(masks[it]);
-    }
-    __syncthreads();
-    if (tid == 0) {
-        int tot = 0;
-        for (int it = 0; it < COMPACT_ITERS; it++)
-            for (int w = 0; w < BLOCK / 64; w++) {
-                int c = s_cnt[it][w];
-                s_cnt[it][w] = tot;
-                tot += c;
-            }
-        s_base = tot ? atomicAdd(out_count, tot) : 0;
-    }
-    __syncthreads();
-    const int base = s_base;
-    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-#pragma unroll
-    for (int it = 0; it < COMPACT_ITERS; it++) {
-        const unsigned long long m = masks[it];
-        if ((m >> lane) & 1ull) out[base + s_cnt[it][wave] + __popcll(m & lt)] = value[it];
-    }
-    __syncthreads(); // s_cnt and s_base are reused by the next chunk
-    }
-}
-
 __global__ void fill_grey_kernel(uint32_t *__restrict__ fb, int n)
 {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) fb[i] = 0xff1a1a1au;
@@ -387,44 +308,6 @@ __device__ __forceinline__ v3 vpos(const rt_vertex *__restrict__ v, int i)
 // intersect, part 1 of 3  ("OpenGL Raytracer/rayintersect_cs.glsl":6-12)
 // ---------------------------------------------------------------------------
 
-__global__ __launch_bounds__(BLOCK) void intersect_setup_kernel(RaySoA r, const int *__restrict__ list,
-                                                                const int *__restrict__ count, int n_fixed, Job job,
-                                                                unsigned long long *__restrict__ best, int shared,
-                                                                SharedOrigin so, unsigned int *keys, int *n_out,
-                                                                int *zero_this)
-{
-    const int n = count ? *count : n_fixed;
-    if (n_out && blockIdx.x == 0 && threadIdx.x == 0) *n_out = n; // for the kernel log
-    // a counter that a later kernel of this stage call counts up from zero, and no kernel of this
-    // launch or before it still reads (here: the number of walks handed over)
-    if (zero_this && blockIdx.x == 0 && threadIdx.x == 0) *zero_this = 0;
-    RT_FOR_EACH_SLOT(slot, n) {
-    const int i = list ? list[slot] : slot;
-    v3 o = rtx::V(r.ox[i], r.oy[i], r.oz[i]);
-    const v3 d = rtx::V(r.dx[i], r.dy[i], r.dz[i]);
-    o = rtx::add(o, rtx::muls(d, 0.001f)); // r.origin = r.origin + r.dir * 0.001
-    job.ox[slot] = o.x; job.oy[slot] = o.y; job.oz[slot] = o.z;
-    job.dx[slot] = d.x; job.dy[slot] = d.y; job.dz[slot] = d.z;
-    best[slot] = BEST_NONE;
-    if (shared == 1) prepare_shared(job, slot, o, d, so.origin, so.center, so.radius, so.reach_max, so.sign);
-    if (shared == 2) prepare_general(job, slot, o, d, so.center, so.radius);
-    if (keys) {
-        // the cell under which the band sweep files the ray (rt_grid.h)
-        keys[slot] = rtg::oct_cell_folded(d.x, d.y, d.z, so.key_bits);
-    }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// Rays grouped by a key (the direction cell in which a list files them): out[] = the slots 0..n-1
-// ordered by key, in any order inside a key.  Count per key, exclusive scan (rocprim), scatter with
-// one atomic per ray; n is read on the device.  hist[] must be zero before the count and is zero
-// again after the scatter.
-// ---------------------------------------------------------------------------
-// (Rays of a wavefront often share a key -- neighbouring pixels, one cell -- and atomics on one address are
-// served one after the other: a wavefront issues one atomic per distinct key, on behalf of all its lanes.
-// The lanes are first grouped by key with ballots alone; then all the groups' leaders issue their atomics
-// in ONE instruction, so a wavefront waits for one round trip, not one per key.)
 struct KeyGroup {
     int leader;        // the lowest lane with this lane's key
     unsigned int rank; // lanes with this key below this one
@@ -448,20 +331,169 @@ __device__ __forceinline__ KeyGroup group_by_key(unsigned int key, bool valid, i
     return g;
 }
 
-__global__ __launch_bounds__(BLOCK) void bin_count_kernel(const unsigned int *__restrict__ keys,
-                                                          const int *__restrict__ count, unsigned int *__restrict__ hist)
+// What rt_intersect prepares per slot of its list (rayintersect_cs.glsl:19-21): the ray as the reference
+// traces it, the quantities the filters want, and -- when the launch groups its rays by direction cell --
+// the slot's key, counted into hist[] here (bin_count_kernel's work).  All lanes of a wavefront that are
+// still in the caller's loop call this together; `valid` says whether the lane has a slot.
+__device__ __forceinline__ void intersect_setup_slot(const RaySoA &r, bool valid, int i, int slot, const Job &job,
+                                                     unsigned long long *__restrict__ best, int shared,
+                                                     const SharedOrigin &so, unsigned int *keys,
+                                                     unsigned int *hist)
 {
-    const int n = *count;
-    const int lane = threadIdx.x & 63;
-    for (int base = blockIdx.x * BLOCK; base < n; base += (int)gridDim.x * BLOCK) {
-        const int slot = base + threadIdx.x;
-        const bool valid = slot < n;
-        const unsigned int key = valid ? keys[slot] : 0xffffffffu;
-        const KeyGroup g = group_by_key(key, valid, lane);
-        if (valid && g.leader == lane) atomicAdd(&hist[key], g.size);
+    unsigned int key = 0xffffffffu;
+    if (valid) {
+        v3 o = rtx::V(r.ox[i], r.oy[i], r.oz[i]);
+        const v3 d = rtx::V(r.dx[i], r.dy[i], r.dz[i]);
+        o = rtx::add(o, rtx::muls(d, 0.001f)); // r.origin = r.origin + r.dir * 0.001
+        job.ox[slot] = o.x; job.oy[slot] = o.y; job.oz[slot] = o.z;
+        job.dx[slot] = d.x; job.dy[slot] = d.y; job.dz[slot] = d.z;
+        best[slot] = BEST_NONE;
+        if (shared == 1) prepare_shared(job, slot, o, d, so.origin, so.center, so.radius, so.reach_max, so.sign);
+        if (shared == 2) prepare_general(job, slot, o, d, so.center, so.radius);
+        if (keys) {
+            // the cell under which the band sweep files the ray (rt_grid.h)
+            key = rtg::oct_cell_folded(d.x, d.y, d.z, so.key_bits);
+            keys[slot] = key;
+        }
+    }
+    if (keys && hist) {
+        const KeyGroup g = group_by_key(key, valid, (int)(threadIdx.x & 63));
+        if (valid && g.leader == (int)(threadIdx.x & 63)) atomicAdd(&hist[key], g.size);
     }
 }
 
+__global__ __launch_bounds__(BLOCK) void intersect_setup_kernel(RaySoA r, const int *__restrict__ list,
+                                                                const int *__restrict__ count, int n_fixed, Job job,
+                                                                unsigned long long *__restrict__ best, int shared,
+                                                                SharedOrigin so, unsigned int *keys, unsigned int *hist,
+                                                                int *n_out, int *zero_this)
+{
+    const int n = count ? *count : n_fixed;
+    if (n_out && blockIdx.x == 0 && threadIdx.x == 0) *n_out = n; // for the kernel log
+    // a counter that a later kernel of this stage call counts up from zero, and no kernel of this
+    // launch or before it still reads (here: the number of walks handed over)
+    if (zero_this && blockIdx.x == 0 && threadIdx.x == 0) *zero_this = 0;
+    RT_FOR_EACH_SLOT(slot, n) {
+        intersect_setup_slot(r, true, list ? list[slot] : slot, slot, job, best, shared, so, keys, hist);
+    }
+}
+
+// What rt_color prepares per slot of its list before the loop over the lights.
+__device__ __forceinline__ void color_begin_slot(const RaySoA &r, int i, int slot, const Scratch &s)
+{
+    s.sox[slot] = r.ox[i]; s.soy[slot] = r.oy[i]; s.soz[slot] = r.oz[i];
+    s.lr[slot] = 0.0f; s.lg[slot] = 0.0f; s.lb[slot] = 0.0f;
+    s.lit[slot] = 0;
+}
+
+// ---------------------------------------------------------------------------
+// stream compaction: out[] = the entries that satisfy a predicate; workgroup
+// segments land in arbitrary order, entries keep their order inside a segment of
+// 2048.
+// Rays are visited through `perm`, the enumeration of the frame's pixels in 8x8 tiles
+// (Morton order inside 32x32 blocks), so that 64 consecutive list entries are rays through
+// neighbouring pixels: a wavefront's rays then see the same few triangles.
+//   MODE 0: ray indices i in [0,n) that are live      (primitiveID != -2)   -- before intersect;
+//           the thread that files a ray under its slot prepares the slot too (intersect_setup_slot)
+//   MODE 1: ray indices with a finite origin                               -- before shading;
+//           the others are reference-grey (see color_finish_kernel) and get their pixel here;
+//           the thread that files a ray prepares its slot (color_begin_slot)
+//   MODE 2: slots of in_list (or 0..n-1 when in_list is null) whose shadow ray is not yet
+//           occluded (occ[slot] == 0)                                      -- between shadow chunks
+// ---------------------------------------------------------------------------
+constexpr int COMPACT_ITERS = 8;
+
+struct CompactWork { // what MODE 0 / MODE 1 do for each entry they file (unused members stay zero)
+    Job job;
+    unsigned long long *best;
+    int shared;
+    SharedOrigin so;
+    unsigned int *keys, *hist;
+    Scratch scratch;
+    int *zero_this; // a counter zeroed for a later kernel of the stage call (see intersect_setup_kernel)
+};
+
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void compact_kernel(RaySoA r, const int *__restrict__ perm,
+                                                        const int *__restrict__ in_list,
+                                                        const int *__restrict__ in_count, int n_fixed,
+                                                        const int *__restrict__ occ, int *__restrict__ out,
+                                                        int *__restrict__ out_count, uint32_t *__restrict__ fb,
+                                                        CompactWork work)
+{
+    __shared__ int s_cnt[COMPACT_ITERS][BLOCK / 64];
+    __shared__ int s_base;
+    const int n = in_count ? *in_count : n_fixed;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (work.zero_this && blockIdx.x == 0 && tid == 0) *work.zero_this = 0;
+    // the launch has a fixed number of workgroups; each takes every gridDim.x-th chunk
+    for (int chunk = blockIdx.x * (BLOCK * COMPACT_ITERS); chunk < n; chunk += (int)gridDim.x * (BLOCK * COMPACT_ITERS)) {
+    unsigned long long masks[COMPACT_ITERS];
+    int value[COMPACT_ITERS];
+#pragma unroll
+    for (int it = 0; it < COMPACT_ITERS; it++) {
+        const int i = chunk + it * BLOCK + tid;
+        bool p = false;
+        value[it] = i;
+        if (i < n) {
+            if (MODE == 0) {
+                const int ri = perm[i]; // rays are visited in pixel-tile order
+                value[it] = ri;
+                p = r.id[ri] != -2;
+            } else if (MODE == 1) {
+                const int ri = perm[i];
+                value[it] = ri;
+                float a = r.ox[ri], b = r.oy[ri], c = r.oz[ri];
+                // finite <=> |x| < inf (false for NaN)
+                p = (fabsf(a) < INFINITY) && (fabsf(b) < INFINITY) && (fabsf(c) < INFINITY);
+                if (!p) fb[ri] = 0xff1a1a1au; // vec3(0.1) -> 26, alpha 255
+            } else {
+                const int slot = in_list ? in_list[i] : i;
+                value[it] = slot;
+                p = occ[slot] == 0;
+            }
+        }
+        masks[it] = __ballot(p);
+        if (lane == 0) s_cnt[it][wave] = __popcll(masks[it]);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int tot = 0;
+        for (int it = 0; it < COMPACT_ITERS; it++)
+            for (int w = 0; w < BLOCK / 64; w++) {
+                int c = s_cnt[it][w];
+                s_cnt[it][w] = tot;
+                tot += c;
+            }
+        s_base = tot ? atomicAdd(out_count, tot) : 0;
+    }
+    __syncthreads();
+    const int base = s_base;
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int it = 0; it < COMPACT_ITERS; it++) {
+        const unsigned long long m = masks[it];
+        const bool has = (m >> lane) & 1ull;
+        const int slot = base + s_cnt[it][wave] + __popcll(m & lt);
+        if (has) out[slot] = value[it];
+        if (MODE == 0)
+            intersect_setup_slot(r, has, value[it], slot, work.job, work.best, work.shared, work.so, work.keys, work.hist);
+        if (MODE == 1 && has) color_begin_slot(r, value[it], slot, work.scratch);
+    }
+    __syncthreads(); // s_cnt and s_base are reused by the next chunk
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Rays grouped by a key (the direction cell in which a list files them): out[] = the slots 0..n-1
+// ordered by key, in any order inside a key.  Count per key (by the kernel that forms the keys:
+// intersect_setup_slot, shadow_setup_kernel), exclusive scan (rocprim), scatter; n is read on the
+// device.  hist[] must be zero before the count and is zero again after the scatter.
+// ---------------------------------------------------------------------------
+// (Rays of a wavefront often share a key -- neighbouring pixels, one cell -- and atomics on one address are
+// served one after the other: a wavefront issues one atomic per distinct key, on behalf of all its lanes.
+// The lanes are first grouped by key with ballots alone; then all the groups' leaders issue their atomics
+// in ONE instruction, so a wavefront waits for one round trip, not one per key.)
 __global__ __launch_bounds__(BLOCK) void bin_scatter_kernel(const unsigned int *__restrict__ keys,
                                                             const int *__restrict__ count,
                                                             const unsigned int *__restrict__ off,
@@ -2404,10 +2436,12 @@ __global__ __launch_bounds__(BLOCK) void intersect_finish_kernel(RaySoA r, const
                                                                  const unsigned long long *__restrict__ best,
                                                                  const rt_vertex *__restrict__ verts, int num_tris,
                                                                  Camera cam, float *__restrict__ depth,
-                                                                 unsigned long long *counters, int *zero_this)
+                                                                 unsigned long long *counters, int *zero_this,
+                                                                 int *n_out)
 {
     const int n = count ? *count : n_fixed;
     if (blockIdx.x == 0 && threadIdx.x == 0) add_counter(counters, C_CH_RAYS, (unsigned long long)n);
+    if (n_out && blockIdx.x == 0 && threadIdx.x == 0) *n_out = n; // for the kernel log
     // the list counter of the OTHER stage, which no kernel of this stage call reads: zero for its next use
     if (zero_this && blockIdx.x == 0 && threadIdx.x == 0) *zero_this = 0;
     RT_FOR_EACH_SLOT(slot, n) {
@@ -2468,23 +2502,11 @@ __global__ __launch_bounds__(BLOCK) void intersect_finish_kernel(RaySoA r, const
 // light as origin applies; the exact test uses the reference's own origin
 // (r.origin + lightDir * 1e-7) and direction.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void color_begin_kernel(RaySoA r, const int *__restrict__ list0,
-                                                            const int *__restrict__ count, Scratch s)
-{
-    const int n = *count;
-    RT_FOR_EACH_SLOT(slot, n) {
-        const int i = list0[slot];
-        s.sox[slot] = r.ox[i]; s.soy[slot] = r.oy[i]; s.soz[slot] = r.oz[i];
-        s.lr[slot] = 0.0f; s.lg[slot] = 0.0f; s.lb[slot] = 0.0f;
-        s.lit[slot] = 0;
-    }
-}
-
 // raycol_cs.glsl:39-47
 __global__ __launch_bounds__(BLOCK) void shadow_setup_kernel(const int *__restrict__ count, Scratch s, Job job,
                                                              float lx, float ly, float lz, SharedOrigin so,
                                                              unsigned long long *counters, unsigned int *keys,
-                                                             int *n_out)
+                                                             unsigned int *hist, int *n_out)
 {
     const int n = *count;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -2504,8 +2526,16 @@ __global__ __launch_bounds__(BLOCK) void shadow_setup_kernel(const int *__restri
     job.tmax[slot] = dist;
     s.occ[slot] = (dist < INFINITY) ? 0 : 1; // `lightRay.t > d` can only hold for finite d
     prepare_shared(job, slot, o2, ld, so.origin, so.center, so.radius, so.reach_max, so.sign);
-    // sorted by the cell of the direction in which the light sees them (rt_grid.h)
-    if (keys) keys[slot] = rtg::oct_cell(-ld.x, -ld.y, -ld.z, so.key_bits);
+    // grouped by the cell of the direction in which the light sees them (rt_grid.h); the key is counted
+    // into hist[] here (bin_count_kernel's work; the lanes still in the loop do it together)
+    if (keys) {
+        const unsigned int key = rtg::oct_cell(-ld.x, -ld.y, -ld.z, so.key_bits);
+        keys[slot] = key;
+        if (hist) {
+            const KeyGroup g = group_by_key(key, true, (int)(threadIdx.x & 63));
+            if (g.leader == (int)(threadIdx.x & 63)) atomicAdd(&hist[key], g.size);
+        }
+    }
     }
 }
 
