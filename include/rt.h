@@ -159,6 +159,10 @@ int rt_set_trace_mode(rt_ctx *ctx, int mode /* rt_trace_mode */);
  *   RT_OPT_FAIL_NEXT_STAGE  for tests of a caller's error handling: with a value other than 0 the next
  *                           rt_intersect or rt_color fails with RT_ERR_HIP after it has begun (its timing
  *                           events open, nothing enqueued) and the option returns to 0
+ *   RT_OPT_MOVING_ORIGIN_LEVELS  how many levels coarser (0..4, default 1) the direction cells of an
+ *                           origin are when its previous lists served a single launch before it moved
+ *                           and the frame has fewer than 16 rays per triangle: coarser lists are
+ *                           built faster and read slower
  * RT_OPT_GRID_BITS, RT_OPT_BAND_LIST_MAX and RT_OPT_VOXEL_RES decide what rt_set_mesh builds: after
  * setting one of them the context has no mesh until the next rt_set_mesh. */
 typedef enum rt_option {
@@ -169,7 +173,8 @@ typedef enum rt_option {
     RT_OPT_BAND_LIST_MAX    = 4,
     RT_OPT_VOXEL_RES        = 5,
     RT_OPT_WALK_BUDGET      = 6,
-    RT_OPT_FAIL_NEXT_STAGE  = 7
+    RT_OPT_FAIL_NEXT_STAGE  = 7,
+    RT_OPT_MOVING_ORIGIN_LEVELS = 8
 } rt_option;
 int rt_set_option(rt_ctx *ctx, int option /* rt_option */, long long value);
 

@@ -487,17 +487,33 @@ __global__ __launch_bounds__(BLOCK) void compact_kernel(RaySoA r, const int *__r
 // ---------------------------------------------------------------------------
 // Rays grouped by a key (the direction cell in which a list files them): out[] = the slots 0..n-1
 // ordered by key, in any order inside a key.  Count per key (by the kernel that forms the keys:
-// intersect_setup_slot, shadow_setup_kernel), exclusive scan (rocprim), scatter; n is read on the
+// intersect_setup_slot, shadow_setup_kernel; bin_count_kernel for keys that exist already), exclusive
+// scan (rocprim), scatter; n is read on the
 // device.  hist[] must be zero before the count and is zero again after the scatter.
 // ---------------------------------------------------------------------------
 // (Rays of a wavefront often share a key -- neighbouring pixels, one cell -- and atomics on one address are
 // served one after the other: a wavefront issues one atomic per distinct key, on behalf of all its lanes.
 // The lanes are first grouped by key with ballots alone; then all the groups' leaders issue their atomics
 // in ONE instruction, so a wavefront waits for one round trip, not one per key.)
+__global__ __launch_bounds__(BLOCK) void bin_count_kernel(const unsigned int *__restrict__ keys,
+                                                          const int *__restrict__ count, unsigned int *__restrict__ hist)
+{
+    const int n = *count;
+    const int lane = threadIdx.x & 63;
+    for (int base = blockIdx.x * BLOCK; base < n; base += (int)gridDim.x * BLOCK) {
+        const int slot = base + threadIdx.x;
+        const bool valid = slot < n;
+        const unsigned int key = valid ? keys[slot] : 0xffffffffu;
+        const KeyGroup g = group_by_key(key, valid, lane);
+        if (valid && g.leader == lane) atomicAdd(&hist[key], g.size);
+    }
+}
+
 __global__ __launch_bounds__(BLOCK) void bin_scatter_kernel(const unsigned int *__restrict__ keys,
                                                             const int *__restrict__ count,
                                                             const unsigned int *__restrict__ off,
-                                                            unsigned int *__restrict__ hist, int *__restrict__ out)
+                                                            unsigned int *__restrict__ hist, int *__restrict__ out,
+                                                            const int *__restrict__ vals)
 {
     const int n = *count;
     const int lane = threadIdx.x & 63;
@@ -509,7 +525,7 @@ __global__ __launch_bounds__(BLOCK) void bin_scatter_kernel(const unsigned int *
         unsigned int first = 0;
         if (valid && g.leader == lane) first = atomicSub(&hist[key], g.size) - g.size;
         first = (unsigned int)__shfl((int)first, g.leader, 64);
-        if (valid) out[off[key] + first + g.rank] = slot;
+        if (valid) out[off[key] + first + g.rank] = vals ? vals[slot] : slot; // the entry's payload, or its index
     }
 }
 
@@ -2586,9 +2602,11 @@ __global__ __launch_bounds__(BLOCK) void color_finish_kernel(RaySoA r, const int
                                                              const int *__restrict__ count, Scratch s,
                                                              const rt_vertex *__restrict__ verts, int num_vertices,
                                                              const uint32_t *__restrict__ tex, int tex_w, int tex_h,
-                                                             uint32_t *__restrict__ fb, int *zero_this)
+                                                             uint32_t *__restrict__ fb, int *zero_this, int *n_host)
 {
     const int n = *count;
+    // feedback for the host's choices in later calls (pinned host memory; nobody waits for it)
+    if (n_host && blockIdx.x == 0 && threadIdx.x == 0) *n_host = n;
     // the list counter of the OTHER stage, which no kernel of this stage call reads: zero for its next use
     if (zero_this && blockIdx.x == 0 && threadIdx.x == 0) *zero_this = 0;
     RT_FOR_EACH_SLOT(slot, n) {
