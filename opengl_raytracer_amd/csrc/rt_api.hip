@@ -1147,7 +1147,11 @@ static int launch_traverse_clustered(rt_ctx *c, TraverseParams p, int n_upper, i
         p.walk_count = c->walk_count_d;
         p.walk_budget = c->walk_budget;
         // (walk_count_d was zeroed by the kernel of this stage call that prepared the slots)
-        hipLaunchKernelGGL(traverse_voxel_kernel, dim3(cdiv(n_upper, BLOCK)), dim3(BLOCK), 0, st, p);
+        // a fixed number of wavefronts, each with a run of the list (fewer when even the longest list there
+        // can be gives them less than 64 rays each)
+        const int walk_blocks = cdiv(n_upper, BLOCK) < VOXEL_WAVES / (BLOCK / 64) ? cdiv(n_upper, BLOCK)
+                                                                                  : VOXEL_WAVES / (BLOCK / 64);
+        hipLaunchKernelGGL(traverse_voxel_kernel, dim3(walk_blocks), dim3(BLOCK), 0, st, p);
         HIPCHK(c, hipGetLastError());
         if (!fork) {
             if (int r = klog_end(c, ks)) return r;

@@ -2125,15 +2125,17 @@ __global__ __launch_bounds__(BLOCK) void traverse_bandcell_kernel(TraverseParams
 // Walks differ a lot in length -- most rays hit something after a few cells, a ray that leaves the
 // scene crosses the whole grid -- and a walk is a chain of dependent loads: a lane needs about a
 // microsecond per step, so one long walk holds its wavefront, and the launch, for hundreds of
-// microseconds.  A wavefront therefore stops after p.walk_budget steps of its loop and appends the walks
-// still under way, as (slot, parameter at which the cell they are in was entered), to a list that
-// traverse_voxel_long_kernel takes up: one WAVEFRONT per ray there, 64 cells and 64 triangles at a time.
-// grid = ray blocks of 256.
+// microseconds.  A lane therefore gives a walk up after p.walk_budget steps of the loop and appends it, as
+// (slot, parameter at which the cell it is in was entered), to a list that traverse_voxel_long_kernel
+// takes up: one WAVEFRONT per ray there, 64 cells and 64 triangles at a time.
+// grid = VOXEL_WAVES / 4 workgroups of four independent wavefronts (fewer for short lists).
 // ---------------------------------------------------------------------------
 constexpr int VOXEL_FLUSH_MIN = 16;
 constexpr int VOXEL_BATCH = rtv::LIST_ALIGN; // triangles of a cell's list a lane takes per step of its loop
 constexpr int VOXEL_SEEN = 32; // per lane: triangles remembered as already tested (a triangle is on the lists of
                                // all the cells around it, and a ray meets it in several of them in a row)
+constexpr int VOXEL_REFILL_MIN = 16; // free lanes that make a wavefront take new rays
+constexpr int VOXEL_WAVES = 4096;    // wavefronts of a launch of the walk (four per SIMD)
 
 __global__ __launch_bounds__(BLOCK) void traverse_voxel_kernel(TraverseParams p)
 {
@@ -2143,34 +2145,31 @@ __global__ __launch_bounds__(BLOCK) void traverse_voxel_kernel(TraverseParams p)
     __shared__ int seen[VOXEL_SEEN][BLOCK];
     const int tid = threadIdx.x;
     const int n = p.count ? *p.count : p.n;
-    const int s = blockIdx.x * BLOCK + tid;
-    if ((s & ~63) >= n) return; // the whole wavefront (the launch is laid out for the longest list)
-    const bool valid = s < n;
-    const int sl = valid ? (p.alist ? p.alist[s] : s) : 0;
-#pragma unroll
-    for (int h = 0; h < VOXEL_SEEN; h++) seen[h][tid] = -1;
-    const float qn = __int_as_float(0x7fc00000);
-    float ox = qn, oy = qn, oz = qn, dx = qn, dy = qn, dz = qn, g = qn;
-    float tbest = INFINITY;
-    int idbest = 0;
-    if (valid) {
-        ox = p.job.ox[sl]; oy = p.job.oy[sl]; oz = p.job.oz[sl];
-        dx = p.job.dx[sl]; dy = p.job.dy[sl]; dz = p.job.dz[sl];
-        g = p.job.g[sl];
-        const unsigned long long key = p.best[sl];
-        tbest = __uint_as_float((unsigned int)(key >> 32));
-        idbest = (int)(unsigned int)(key & 0xffffffffull);
-    }
-    const float tfirst = tbest;
-    const int idfirst = idbest;
-    bool active = valid && g > 0.0f;
-    const float hx = dx * g, hy = dy * g, hz = dz * g;
+    // The wavefront's rays: a run of consecutive slots, [nxt, c1).  Walks differ in length by an order of
+    // magnitude and a wavefront issues every instruction for as long as one lane needs it, so a lane whose
+    // walk has ended takes the next ray of the run (when VOXEL_REFILL_MIN lanes are free: taking a ray
+    // costs the wavefront a start-up sequence).  The launch has a fixed number of wavefronts; the runs are
+    // as long as the list needs.
+    const int n_waves = (int)gridDim.x * (BLOCK / 64);
+    const int run = (((n + n_waves - 1) / n_waves) + 63) & ~63;
+    int nxt = (blockIdx.x * (BLOCK / 64) + (tid >> 6)) * run;
+    if (nxt >= n) return; // the whole wavefront
+    const int c1 = min(nxt + run, n);
+    const int budget = p.walk_budget > 0 ? p.walk_budget : (n >= (1 << 19) ? 96 : 48);
     const rtv::Grid &G = p.vox;
+
+    // per-lane state of the ray in hand
+    bool have = false;   // the lane holds a ray
+    bool active = false; // ... and its walk is under way
+    bool gave_up = false; // ... or was cut short by the budget
+    int sl = 0, own_steps = 0;
+    float ox = 0.0f, oy = 0.0f, oz = 0.0f, dx = 0.0f, dy = 0.0f, dz = 0.0f, hx = 0.0f, hy = 0.0f, hz = 0.0f;
+    float tbest = INFINITY, tfirst = INFINITY, inv_dn = 0.0f;
+    int idbest = 0, idfirst = 0;
     rtv::Walk w{};
-    if (active) active = rtv::walk_start(G, ox, oy, oz, dx, dy, dz, w);
-    // A walk is latency-bound -- every step depends on loads that depend on the step before -- and the
-    // launch lasts as long as its longest walk.  So a lane takes B triangles per step of its loop, and the
-    // loads are staggered so that a step waits for one round trip only:
+    // A walk is latency-bound -- every step depends on loads that depend on the step before.  So a lane
+    // takes B triangles per step of its loop, and the loads are staggered so that a step waits for one
+    // round trip only:
     //   * the walk itself stands one cell ahead of the list being read: the bounds of the next cell's list
     //     (n_idx, n_end) are requested when the current cell is entered and have arrived when it is left;
     //   * the indices of the NEXT batch of triangles are requested together with the records of the
@@ -2180,7 +2179,6 @@ __global__ __launch_bounds__(BLOCK) void traverse_voxel_kernel(TraverseParams p)
     unsigned int idx = 0, end = 0, n_idx = 0, n_end = 0;
     bool more = false;
     float n_enter = 0.0f, enter = 0.0f;
-    const float inv_dn = w.inv_dn;
     auto look_ahead = [&]() {
         more = rtv::walk_step(G, ox, oy, oz, w);
         n_enter = w.t_enter;
@@ -2214,19 +2212,8 @@ __global__ __launch_bounds__(BLOCK) void traverse_voxel_kernel(TraverseParams p)
     };
 #pragma unroll
     for (int k = 0; k < B; k++) { tri[k] = -1; has[k] = false; }
-    if (active) {
-        const int cell = rtv::cell_index(G, w);
-        idx = p.vox_off[cell];
-        end = p.vox_off[cell + 1];
-        enter = w.t_enter;
-        look_ahead();
-    }
-    next_batch();
     int cand = -1;
-    unsigned long long n_cand = 0, n_slow = 0;
-#ifdef RT_DBG_VOXEL
-    const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime();
-#endif
+    unsigned long long n_cand = 0, n_slow = 0, n_rays = 0;
 
     // the reference arithmetic on every lane's candidate
     auto flush = [&]() {
@@ -2243,12 +2230,70 @@ __global__ __launch_bounds__(BLOCK) void traverse_voxel_kernel(TraverseParams p)
         cand = -1;
     };
 
-    int steps = 0;
-    // (a small launch is all latency: it hands over sooner)
-    const int budget = p.walk_budget > 0 ? p.walk_budget : (n >= (1 << 19) ? 96 : 48);
-    while (any64(active) && steps < budget) {
-        steps++;
+    for (;;) {
+        // ---- lanes whose walk has ended hand in their ray and take the next one of the run
+        const unsigned long long idle = __builtin_amdgcn_ballot_w64(!active);
+        if (idle == ~0ull || (nxt < c1 && __popcll(idle) >= VOXEL_REFILL_MIN)) {
+            if (any64(!active && cand >= 0)) flush();
+            if (have && !active) {
+                const bool spill = gave_up; // out of budget: the walk goes on the list, from the cell of the batch
+                const unsigned long long left = __builtin_amdgcn_ballot_w64(spill); // that was next
+                if (left) {
+                    int base = 0;
+                    if ((tid & 63) == __builtin_ctzll(left)) base = atomicAdd(p.walk_count, __popcll(left));
+                    base = __shfl(base, __builtin_ctzll(left), 64);
+                    if (spill) {
+                        const int pos = base + lanes_below(left);
+                        p.walk_slot[pos] = sl;
+                        p.walk_t[pos] = enter;
+                    }
+                }
+                if (tbest < tfirst || (tbest == tfirst && idbest < idfirst)) {
+                    const unsigned long long key =
+                        ((unsigned long long)__float_as_uint(tbest) << 32) | (unsigned long long)(unsigned int)idbest;
+                    atomicMin(&p.best[sl], key);
+                }
+                have = false;
+            }
+            const unsigned long long free_lanes = __builtin_amdgcn_ballot_w64(!have);
+            const int mine = nxt + lanes_below(free_lanes);
+            const bool fresh = !have && mine < c1;
+            nxt = min(nxt + __popcll(free_lanes), c1);
+            if (fresh) {
+                sl = p.alist ? p.alist[mine] : mine;
+                ox = p.job.ox[sl]; oy = p.job.oy[sl]; oz = p.job.oz[sl];
+                dx = p.job.dx[sl]; dy = p.job.dy[sl]; dz = p.job.dz[sl];
+                const float g = p.job.g[sl];
+                hx = dx * g; hy = dy * g; hz = dz * g;
+                const unsigned long long key = p.best[sl];
+                tbest = tfirst = __uint_as_float((unsigned int)(key >> 32));
+                idbest = idfirst = (int)(unsigned int)(key & 0xffffffffull);
+#pragma unroll
+                for (int h = 0; h < VOXEL_SEEN; h++) seen[h][tid] = -1;
+                have = true;
+                gave_up = false;
+                own_steps = 0;
+                cand = -1;
+                idx = end = 0;
+                more = false;
+                // rays outside the band records' range (g <= 0) and rays no filter passes (g NaN) do not walk
+                active = g > 0.0f && rtv::walk_start(G, ox, oy, oz, dx, dy, dz, w);
+                inv_dn = w.inv_dn;
+                if (active) {
+                    const int cell = rtv::cell_index(G, w);
+                    idx = p.vox_off[cell];
+                    end = p.vox_off[cell + 1];
+                    enter = w.t_enter;
+                    look_ahead();
+                }
+                next_batch();
+            }
+            n_rays += __popcll(__builtin_amdgcn_ballot_w64(fresh));
+            if (!any64(have)) break;
+            if (!any64(active)) continue; // rays that do not walk: hand them in, take more
+        }
         n_slow++;
+        if (active) own_steps++;
         if (__popcll(__builtin_amdgcn_ballot_w64(cand >= 0)) >= VOXEL_FLUSH_MIN) flush();
         // nothing in the batch's cell or beyond can matter any more: the walk ends
         if (active && rtv::walk_done_at(G, inv_dn, enter, tbest)) active = false;
@@ -2285,39 +2330,17 @@ __global__ __launch_bounds__(BLOCK) void traverse_voxel_kernel(TraverseParams p)
             if (any64(pass[k] && cand >= 0)) flush(); // a lane needs its slot
             if (pass[k] && cur[k] != cand) cand = cur[k];
         }
-    }
-    flush();
-
-    // out of budget: the walks still under way go on the list, from the cell of the batch that was next
-    {
-        const unsigned long long left = __builtin_amdgcn_ballot_w64(active);
-        if (left) {
-            int base = 0;
-            if ((tid & 63) == 0) base = atomicAdd(p.walk_count, __popcll(left));
-            base = __builtin_amdgcn_readfirstlane(base);
-            if (active) {
-                const int pos = base + lanes_below(left);
-                p.walk_slot[pos] = sl;
-                p.walk_t[pos] = enter;
-            }
+        // out of budget: the ray is handed to the kernel that gives each long walk a wavefront
+        if (active && own_steps >= budget) {
+            active = false;
+            gave_up = true;
         }
     }
 
     if ((tid & 63) == 0) {
         add_counter(p.counters, C_CH_CAND, n_cand);
         add_counter(p.counters, C_CH_SLOW, n_slow);
-        add_counter(p.counters, C_CH_PAIRS, (unsigned long long)min(64, n - (s & ~63)) * (unsigned long long)p.num_tris);
-#ifdef RT_DBG_VOXEL
-        atomicMax(p.counters + 5, n_slow);
-        atomicMax(p.counters + 7, (unsigned long long)(__builtin_amdgcn_s_memtime() - dbg_t0));
-        atomicAdd(p.counters + 8 + 3, n_slow);
-        atomicAdd(p.counters + 8 + 5, 1ull);
-#endif
-    }
-    if (valid && (tbest < tfirst || (tbest == tfirst && idbest < idfirst))) {
-        const unsigned long long key =
-            ((unsigned long long)__float_as_uint(tbest) << 32) | (unsigned long long)(unsigned int)idbest;
-        atomicMin(&p.best[sl], key);
+        add_counter(p.counters, C_CH_PAIRS, n_rays * (unsigned long long)p.num_tris);
     }
 }
 
