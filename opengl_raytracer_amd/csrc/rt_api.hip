@@ -147,6 +147,8 @@ struct rt_ctx {
     // directions in which a light sees them -- the next shading pass does not sort its shadow rays
     bool hits_follow_pixels = false;
     bool rays_valid = false;
+    int *chunk_filed_d[2] = {nullptr, nullptr}; // entries each chunk of the compaction filed (rt_intersect's, rt_color's)
+    bool chunk_filed_valid[2] = {false, false}; // ... in the last pass over the rays now in the buffer
 
     int *list = nullptr;    // compacted ray indices (live rays / rays with a finite origin)
     int *alist[2] = {nullptr, nullptr}; // shadow rays still unoccluded (slots), ping-pong
@@ -370,6 +372,8 @@ extern "C" int rt_create(rt_ctx **out, int hip_device, int width, int height)
     CRCHK(hipMalloc(&c->walk_count_d, sizeof(int)));
     CRCHK(hipMalloc(&c->alist[0], c->cap * sizeof(int)));
     CRCHK(hipMalloc(&c->alist[1], c->cap * sizeof(int)));
+    for (int k = 0; k < 2; k++)
+        CRCHK(hipMalloc(&c->chunk_filed_d[k], (c->cap / (BLOCK * COMPACT_ITERS) + 2) * sizeof(int)));
     CRCHK(hipMalloc(&c->sort_keys, c->cap * sizeof(unsigned int)));
     CRCHK(hipMalloc(&c->sort_slots, c->cap * sizeof(int)));
     {
@@ -477,6 +481,8 @@ extern "C" void rt_destroy(rt_ctx *c)
     (void)hipFree(c->walk_slot_d);
     (void)hipFree(c->walk_t_d);
     (void)hipFree(c->walk_count_d);
+    (void)hipFree(c->chunk_filed_d[0]);
+    (void)hipFree(c->chunk_filed_d[1]);
     (void)hipFree(c->alist[0]);
     (void)hipFree(c->alist[1]);
     (void)hipFree(c->sort_keys);
@@ -775,6 +781,7 @@ extern "C" int rt_set_row_tiles(rt_ctx *c, int tile_rows, int first_tile, int ti
     c->n_rays = c->local_rows * c->width;
     c->feedback_h[0] = -1; // counts of another share of the frame
     c->rays_valid = false;
+    c->chunk_filed_valid[0] = c->chunk_filed_valid[1] = false;
     c->rays_share_camera_origin = false;
     if (c->local_rows) return upload_row_map(c);
     return RT_OK;
@@ -923,6 +930,7 @@ extern "C" int rt_raygen(rt_ctx *c)
     }
     if (int r = stage_end(c, slot)) return r;
     c->rays_valid = true;
+    c->chunk_filed_valid[0] = c->chunk_filed_valid[1] = false; // other rays
     c->rays_share_camera_origin = true;
     return RT_OK;
 }
@@ -1444,8 +1452,10 @@ extern "C" int rt_intersect(rt_ctx *c)
             work.zero_this = c->walk_count_d;
             hipLaunchKernelGGL((compact_kernel<0>), dim3(list_blocks(c->n_rays, BLOCK * COMPACT_ITERS)), dim3(BLOCK), 0,
                                c->stream, c->rays, (const int *)c->perm_d, (const int *)nullptr, (const int *)nullptr,
-                               c->n_rays, (const int *)nullptr, c->list, c->count_d, (uint32_t *)nullptr, work);
+                               c->n_rays, (const int *)nullptr, c->list, c->count_d, (uint32_t *)nullptr, work,
+                               c->chunk_filed_d[0], c->chunk_filed_valid[0] ? 1 : 0);
             HIPCHK(c, hipGetLastError());
+            c->chunk_filed_valid[0] = true;
             list = c->list;
             count = c->count_d;
             n_slot = next_n_slot(c);
@@ -1531,8 +1541,10 @@ extern "C" int rt_color(rt_ctx *c)
             work.scratch = c->scratch;
             hipLaunchKernelGGL((compact_kernel<1>), dim3(list_blocks(c->n_rays, BLOCK * COMPACT_ITERS)), dim3(BLOCK), 0,
                                c->stream, c->rays, (const int *)c->perm_d, (const int *)nullptr, (const int *)nullptr,
-                               c->n_rays, (const int *)nullptr, c->list, c->count_d + 1, c->fb, work);
+                               c->n_rays, (const int *)nullptr, c->list, c->count_d + 1, c->fb, work,
+                               c->chunk_filed_d[1], c->chunk_filed_valid[1] ? 1 : 0);
             HIPCHK(c, hipGetLastError());
+            c->chunk_filed_valid[1] = true;
             const int n0 = c->n_rays;
             const int *cnt0 = c->count_d + 1;
             const dim3 g0(list_blocks(n0, BLOCK));
@@ -1602,7 +1614,7 @@ extern "C" int rt_color(rt_ctx *c)
                         hipLaunchKernelGGL((compact_kernel<2>), dim3(list_blocks(n0, BLOCK * COMPACT_ITERS)),
                                            dim3(BLOCK), 0, c->stream, c->rays, (const int *)nullptr, alist, acount, n0,
                                            (const int *)c->scratch.occ, c->alist[pp], ocount, (uint32_t *)nullptr,
-                                           CompactWork{});
+                                           CompactWork{}, (int *)nullptr, 0);
                         HIPCHK(c, hipGetLastError());
                         alist = c->alist[pp];
                         acount = ocount;
@@ -1701,6 +1713,7 @@ extern "C" int rt_write_rays(rt_ctx *c, const rt_ray *in)
     (void)hipFree(tmp);
     if (e != hipSuccess) return fail(c, RT_ERR_HIP, "rt_write_rays: %s", hipGetErrorString(e));
     c->rays_valid = true;
+    c->chunk_filed_valid[0] = c->chunk_filed_valid[1] = false; // other rays
     c->rays_share_camera_origin = false;
     return RT_OK;
 }
@@ -1790,5 +1803,6 @@ extern "C" int rt_bind_framebuffer(rt_ctx *c, void *device_rgba8)
     if (int r = use_device(c)) return r;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->fb = device_rgba8 ? reinterpret_cast<uint32_t *>(device_rgba8) : c->fb_own;
+    c->chunk_filed_valid[1] = false; // the new framebuffer has not seen the grey pixels of skipped chunks
     return RT_OK;
 }

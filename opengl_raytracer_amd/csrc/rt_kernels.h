@@ -419,7 +419,8 @@ __global__ __launch_bounds__(BLOCK) void compact_kernel(RaySoA r, const int *__r
                                                         const int *__restrict__ in_count, int n_fixed,
                                                         const int *__restrict__ occ, int *__restrict__ out,
                                                         int *__restrict__ out_count, uint32_t *__restrict__ fb,
-                                                        CompactWork work)
+                                                        CompactWork work, int *__restrict__ chunk_filed,
+                                                        int skip_empty)
 {
     __shared__ int s_cnt[COMPACT_ITERS][BLOCK / 64];
     __shared__ int s_base;
@@ -428,6 +429,12 @@ __global__ __launch_bounds__(BLOCK) void compact_kernel(RaySoA r, const int *__r
     if (work.zero_this && blockIdx.x == 0 && tid == 0) *work.zero_this = 0;
     // the launch has a fixed number of workgroups; each takes every gridDim.x-th chunk
     for (int chunk = blockIdx.x * (BLOCK * COMPACT_ITERS); chunk < n; chunk += (int)gridDim.x * (BLOCK * COMPACT_ITERS)) {
+    // chunk_filed[]: how many entries of each chunk were filed.  The sets MODE 0 and MODE 1 file only shrink
+    // from pass to pass (a dead ray stays dead, a ray without a finite origin never gets one), so a chunk
+    // that filed nothing last time -- most of a frame whose objects cover a part of it -- is skipped
+    // (skip_empty: the counts are those of the last pass over the same rays).
+    const int chunk_id = chunk / (BLOCK * COMPACT_ITERS);
+    if (chunk_filed && skip_empty && chunk_filed[chunk_id] == 0) continue;
     unsigned long long masks[COMPACT_ITERS];
     int value[COMPACT_ITERS];
 #pragma unroll
@@ -466,6 +473,7 @@ __global__ __launch_bounds__(BLOCK) void compact_kernel(RaySoA r, const int *__r
                 tot += c;
             }
         s_base = tot ? atomicAdd(out_count, tot) : 0;
+        if (chunk_filed) chunk_filed[chunk_id] = tot;
     }
     __syncthreads();
     const int base = s_base;
@@ -2052,16 +2060,36 @@ __global__ __launch_bounds__(BLOCK) void traverse_bandcell_kernel(TraverseParams
         }
         return r;
     };
+    // (the first rays of the step's cell stay in scalar registers over the steps of the cell: a list is
+    // several steps long, and fetching a ray from its lane costs as much as testing it)
+    constexpr int HELD = 4;
+    float held[HELD][6];
+    int held_lane[HELD];
+#pragma unroll
+    for (int k = 0; k < HELD; k++) {
+        held_lane[k] = -1;
+#pragma unroll
+        for (int j = 0; j < 6; j++) held[k][j] = 0.0f;
+    }
     auto test_step = [&](const Step &st, const Recs &rc) {
         const float4 m1 = rc.m1, m2 = rc.m2;
         const int tri = __float_as_int(m2.w);
         const bool member = tri >= 0 && m1.w != 2.0f; // not padding, not "never accepted"
         unsigned long long m = st.group;
-        while (m) {
-            const int r = __builtin_ctzll(m);
-            m &= m - 1;
-            const float rbx = readlane_f(bx, r), rby = readlane_f(by, r), rbz = readlane_f(bz, r);
-            const float rox = readlane_f(ox, r), roy = readlane_f(oy, r), roz = readlane_f(oz, r);
+        if (st.base == 0) { // a new cell: its first rays
+            unsigned long long g = st.group;
+#pragma unroll
+            for (int k = 0; k < HELD; k++) {
+                held_lane[k] = g ? __builtin_ctzll(g) : -1;
+                if (g) {
+                    const int r = held_lane[k];
+                    g &= g - 1;
+                    held[k][0] = readlane_f(bx, r); held[k][1] = readlane_f(by, r); held[k][2] = readlane_f(bz, r);
+                    held[k][3] = readlane_f(ox, r); held[k][4] = readlane_f(oy, r); held[k][5] = readlane_f(oz, r);
+                }
+            }
+        }
+        auto test_ray = [&](int r, float rbx, float rby, float rbz, float rox, float roy, float roz) {
             const float t0 = fmaf(m1.z, rbz, fmaf(m1.y, rby, m1.x * rbx));
             const float h0 = fmaf(m2.z, roz, fmaf(m2.y, roy, fmaf(m2.x, rox, -m1.w)));
             const bool in = member && fmaxf(fabsf(t0), fabsf(h0)) < 1.0f;
@@ -2071,6 +2099,19 @@ __global__ __launch_bounds__(BLOCK) void traverse_bandcell_kernel(TraverseParams
                 qcount += __popcll(h);
                 if (qcount > GRID_QCAP - 64) drain(false);
             }
+        };
+#pragma unroll
+        for (int k = 0; k < HELD; k++)
+            if (held_lane[k] >= 0) {
+                test_ray(held_lane[k], held[k][0], held[k][1], held[k][2], held[k][3], held[k][4], held[k][5]);
+                m &= m - 1; // the held rays are the group's lowest lanes, in order
+            }
+        while (m) {
+            const int r = __builtin_ctzll(m);
+            m &= m - 1;
+            const float rbx = readlane_f(bx, r), rby = readlane_f(by, r), rbz = readlane_f(bz, r);
+            const float rox = readlane_f(ox, r), roy = readlane_f(oy, r), roz = readlane_f(oz, r);
+            test_ray(r, rbx, rby, rbz, rox, roy, roz);
         }
         n_slow += __popcll(st.group);
     };
