@@ -361,3 +361,71 @@ def test_stage_that_fails_after_it_began_leaves_timers_and_context_usable(rt, or
         g.render(2); c.render(2)
         same("after a failed stage call", g, c)
         assert all(m > 0 for m in g.stage_ms())
+
+
+def _sparse_scene():
+    """A small soup in one corner of a large frame: most chunks of the frame never file a ray."""
+    from opengl_raytracer_amd import scenes
+    mesh = scenes.triangle_soup(3000, seed=77, extent=0.35, size=0.06)
+    mesh["pos"][:, 0] += 0.9
+    mesh["pos"][:, 1] -= 0.6
+    return mesh, scenes.look_at_camera((0.0, 0.0, -3.0), (0.0, 0.0, 0.0))
+
+
+def test_rays_rewritten_between_passes_are_all_visited(rt, oracle_mod):
+    """Compaction skips the parts of the frame that filed nothing in the pass before; rays written by the
+    caller in between (dead pixels revived, aimed at the mesh) must be found again."""
+    from opengl_raytracer_amd import scenes
+    mesh, cam = _sparse_scene()
+    w, h = 512, 256
+    g, c = rt.RayTracer(w, h), oracle_mod.Oracle(w, h, threads=16)
+    with g:
+        for o in (g, c):
+            o.set_mesh(mesh)
+            o.set_texture(scenes.noise_texture(64, 64))
+            o.set_lights(scenes.default_lights(), 2)
+            o.set_camera(*cam)
+        g.render(2); c.render(2)
+        same("two passes", g, c)
+        rays = c.read_rays()
+        dead = rays["primitiveID"] == -2
+        assert dead.mean() > 0.6                      # most of the frame
+        # every dead ray comes back to life, from the camera towards the soup's corner
+        rs = np.random.RandomState(5)
+        k = int(dead.sum())
+        rays["origin"][dead] = np.float32([0.0, 0.0, -3.0])
+        d = np.float32([0.9, -0.6, 3.0]) + rs.uniform(-0.3, 0.3, size=(k, 3)).astype(np.float32)
+        rays["dir"][dead] = d / np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+        rays["primitiveID"][dead] = -1
+        rays["t"][dead] = np.float32(np.inf)
+        g.write_rays(rays); c.write_rays(rays)
+        for o in (g, c):
+            o.intersect(); o.color(); o.intersect(); o.color()
+        same("after the rewrite", g, c)
+        assert (c.read_rays()["primitiveID"][dead] >= 0).mean() > 0.2   # and many of them hit
+
+
+def test_framebuffer_bound_between_passes_gets_every_pixel(rt, oracle_mod):
+    """A framebuffer bound after the first pass has not seen the grey pixels that pass wrote: the next
+    rt_color must write the whole frame into it, skipped parts included."""
+    import torch
+    from opengl_raytracer_amd import scenes
+    mesh, cam = _sparse_scene()
+    w, h = 512, 256
+    dev = torch.device("cuda", 0)
+    g, c = rt.RayTracer(w, h), oracle_mod.Oracle(w, h, threads=16)
+    with g:
+        for o in (g, c):
+            o.set_mesh(mesh)
+            o.set_texture(scenes.noise_texture(64, 64))
+            o.set_lights(scenes.default_lights(), 1)
+            o.set_camera(*cam)
+        g.render(2); c.render(2)
+        late = torch.zeros((h, w, 4), dtype=torch.uint8, device=dev)
+        g.bind_framebuffer(late.data_ptr())
+        for o in (g, c):
+            o.intersect(); o.color()
+        g.sync()
+        assert np.array_equal(late.cpu().numpy(), c.read_pixels())
+        same("rays", g, c, pixels=False)
+        g.bind_framebuffer(0)
