@@ -260,11 +260,26 @@ def spawn_ranks(args):
                    MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
+    # a rank that fails must not leave the others waiting in a collective for ever
+    import threading
+    out = []
+    reader = threading.Thread(target=lambda: out.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = 0
+    while any(p.poll() is None for p in procs):
+        bad = [p.returncode for p in procs if p.poll() not in (None, 0)]
+        if bad:
+            failed = abs(bad[0])
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            break
+        time.sleep(0.05)
     codes = [p.wait() for p in procs]
-    sys.stdout.write(out.decode())
+    reader.join(timeout=10)
+    sys.stdout.write(b"".join(out).decode())
     sys.stdout.flush()
-    return max(abs(c) for c in codes)
+    return failed or max(abs(c) for c in codes)
 
 
 def main():
@@ -284,6 +299,9 @@ def main():
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="context option (a key of opengl_raytracer_amd._native.OPTIONS), e.g. --opt grid_bits=8")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the gather (nccl = RCCL)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal on a box with fewer GPUs than ranks: rank r renders on GPU r %% (GPUs present); "
+                         "use with --backend gloo (RCCL wants a GPU per rank)")
     ap.add_argument("--renderer", choices=("hip", "oracle"), default="hip",
                     help="oracle: the CPU restatement stands in for the GPU (tests of this program's launcher only)")
     args = ap.parse_args()
@@ -299,9 +317,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     on_gpu = args.renderer == "hip"
+    if on_gpu and args.share_gpu:
+        local_rank %= max(torch.cuda.device_count(), 1)
     if on_gpu:
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank) if on_gpu else torch.device("cpu")
+    # where the pixels are gathered from: device tensors over RCCL; host tensors with any other backend
+    shard_dev = dev if (on_gpu and args.backend == "nccl") else torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if on_gpu and args.backend == "nccl":
@@ -328,15 +350,15 @@ def main():
         mode = "tiles" if wl["kind"] == "tiles" else "batch"
     scaling = "strong"
     if wl["kind"] == "tiles" and (world == 1 or mode == "tiles"):
-        job = sharding.TileShardedFrame(g, wl["width"], wl["height"], dev, bind_device_framebuffer=on_gpu)
+        job = sharding.TileShardedFrame(g, wl["width"], wl["height"], shard_dev, bind_device_framebuffer=on_gpu)
         shard_desc = f"image tiles of {job.tile_rows} rows, interleaved over {world} rank(s), gathered to rank 0"
     elif wl["kind"] == "tiles":
         # one whole frame of the workload per rank per step
-        job = sharding.FrameBatch(g, wl["width"], wl["height"], wl["cams"] * world, dev, bind_device_framebuffer=on_gpu)
+        job = sharding.FrameBatch(g, wl["width"], wl["height"], wl["cams"] * world, shard_dev, bind_device_framebuffer=on_gpu)
         shard_desc = f"frame batch: {world} frames per step, one per rank, gathered to rank 0"
         scaling = "weak"
     else:
-        job = sharding.FrameBatch(g, wl["width"], wl["height"], wl["cams"], dev, bind_device_framebuffer=on_gpu)
+        job = sharding.FrameBatch(g, wl["width"], wl["height"], wl["cams"], shard_dev, bind_device_framebuffer=on_gpu)
         shard_desc = f"frame batch: view k on rank k % {world}, frames gathered to rank 0"
 
     def sync_all():
@@ -380,8 +402,8 @@ def main():
         log, stage_ms = [], [0.0, 0.0, 0.0]
     tot = torch.tensor([cnt["closest_rays"], cnt["shadow_rays"], cnt["closest_pairs"], cnt["shadow_pairs"],
                         cnt["closest_candidates"], cnt["shadow_candidates"], cnt["closest_slow_steps"],
-                        cnt["shadow_slow_steps"]], dtype=torch.float64, device=dev)
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+                        cnt["shadow_slow_steps"]], dtype=torch.float64, device=shard_dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=shard_dev)
     if world > 1:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
