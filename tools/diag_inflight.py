@@ -1,0 +1,47 @@
+"""Frames in flight on one GPU: K contexts (each with its own stream) take the frames of a sequence in
+turn, so that the dependent kernel chains of consecutive frames overlap.  Prints the time per frame for
+K = 1, 2, 3, ... for the whole frame and for one rank's share of a tile split
+(usage: WORLD=8 RANK=0 INFLIGHT=1,2,3 python tools/diag_inflight.py [workload])."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.getcwd())
+import opengl_raytracer_amd as rt
+from bench import workload, setup_scene
+
+wl = workload(sys.argv[1] if len(sys.argv) > 1 else "soup64k_4k_p6")
+world = int(os.environ.get("WORLD", "8"))
+rank = int(os.environ.get("RANK", "0"))
+ks = [int(x) for x in os.environ.get("INFLIGHT", "1,2,3").split(",")]
+frames = int(os.environ.get("FRAMES", "12"))
+
+ctxs = []
+for _ in range(max(ks)):
+    g = rt.RayTracer(wl["width"], wl["height"])
+    setup_scene(g, wl)
+    ctxs.append(g)
+
+
+def run(k, tile_rows, r, w):
+    use = ctxs[:k]
+    for g in use:
+        g.set_row_tiles(tile_rows, r, w)
+        g.render(wl["passes"])
+    for g in use:
+        g.sync()
+    t0 = time.perf_counter()
+    for f in range(frames):
+        use[f % k].render(wl["passes"])
+    for g in use:
+        g.sync()
+    return (time.perf_counter() - t0) / frames * 1e3
+
+
+for k in ks:
+    print("frames in flight %d: whole frame %.3f ms per frame" % (k, run(k, wl["height"], 0, 1)), flush=True)
+for k in ks:
+    print("frames in flight %d: share of rank %d of %d: %.3f ms per frame" % (k, rank, world, run(k, 15, rank, world)),
+          flush=True)
+for g in ctxs:
+    g.close()
