@@ -178,12 +178,14 @@ def named_launches(log, in_turn):
 
 
 def kernel_rooflines(g, job, wl, workload_name):
-    """One more frame after the timed region with the two kernels of a bounce pass one after the other
-    (each launch then has a duration of its own, from the hipEvent pair around it on the library's
-    stream), grouped by kernel.  For each: the executed VALU issue fraction -- wave-instructions per
-    launch (committed PMC summary) / live duration / issue peak -- which cannot exceed 1."""
+    """Two more frames after the timed region, on ONE context with nothing beside it, with the kernels of a
+    bounce pass one after the other and an event pair around every traversal launch (each launch then has a
+    duration of its own), grouped by kernel.  For each: the executed VALU issue fraction --
+    wave-instructions per launch (committed PMC summary) / live duration / issue peak -- which cannot
+    exceed 1."""
     counters, source = committed_counters(workload_name)
     g.set_option("sweeps_in_turn", 1)
+    g.set_option("kernel_timing", 1)
     try:
         job.render(wl["passes"])
         g.sync()
@@ -193,6 +195,7 @@ def kernel_rooflines(g, job, wl, workload_name):
         log = g.kernel_log()
     finally:
         g.set_option("sweeps_in_turn", 0)
+        g.set_option("kernel_timing", 0)
         g.counters()
         g.stage_ms()
     groups = {}
@@ -220,6 +223,7 @@ def exact_mode_roofline(g, job, wl):
     (ray, triangle) pair, vertices streamed through LDS tiles) on every 32nd row tile of the frame, two
     passes; its closest-hit launches against the FP32 vector peak."""
     g.set_trace_mode(1)
+    g.set_option("kernel_timing", 1)
     try:
         g.set_row_tiles(8, 0, 32)
         g.render(1); g.sync(); g.kernel_log()
@@ -227,6 +231,7 @@ def exact_mode_roofline(g, job, wl):
         log = g.kernel_log()
     finally:
         g.set_trace_mode(2)
+        g.set_option("kernel_timing", 0)
         g.set_row_tiles(job.tile_rows, 0, 1)
         g.counters(); g.stage_ms()
     out = []
@@ -294,6 +299,13 @@ def main():
     ap.add_argument("--trace-mode", type=int, default=2, help="0 filtered, 1 exact, 2 clustered (default)")
     ap.add_argument("--sweeps-in-turn", action="store_true",
                     help="the two kernels of a bounce pass one after the other in the timed region too (for profiles)")
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="contexts per GPU that take the frames (or views) of the sequence in turn, each on a stream "
+                         "of its own, so that the kernel chains of consecutive frames overlap (1: one frame at a time; "
+                         "0: 2 for the single-frame workloads -- two contexts use the four hardware queues of a process "
+                         "-- and 3 for the view batch, whose single pass uses one stream per context)")
+    ap.add_argument("--kernel-timing", action="store_true",
+                    help="event pairs around every traversal launch of the timed region too (for profiles)")
     ap.add_argument("--sharding", choices=("auto", "batch", "tiles"), default="auto",
                     help="N > 1: one frame in row tiles (default for single-frame workloads), or whole frames per rank")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
@@ -322,6 +334,9 @@ def main():
     if on_gpu:
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank) if on_gpu else torch.device("cpu")
+    if on_gpu:
+        # not HIP's default stream: work on it does not run beside work on other streams
+        torch.cuda.set_stream(torch.cuda.Stream(dev))
     # where the pixels are gathered from: device tensors over RCCL; host tensors with any other backend
     shard_dev = dev if (on_gpu and args.backend == "nccl") else torch.device("cpu")
     if world > 1:
@@ -334,49 +349,70 @@ def main():
         print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
 
     wl = workload(args.workload)
+    # frames in flight need framebuffers on the device (pixels that go through the host are copied in turn)
+    in_flight = args.frames_in_flight if args.frames_in_flight > 0 else (2 if wl["kind"] == "tiles" else 3)
+    if not (on_gpu and shard_dev.type == "cuda"):
+        in_flight = 1
     if on_gpu:
         import opengl_raytracer_amd as rt
         opts = {k: int(v) for k, v in (o.split("=", 1) for o in args.opt)}
-        g = rt.RayTracer(wl["width"], wl["height"], device=local_rank, options=opts)
-        g.set_trace_mode(args.trace_mode)
-        if args.sweeps_in_turn:
-            g.set_option("sweeps_in_turn", 1)
+        gs = [rt.RayTracer(wl["width"], wl["height"], device=local_rank, options=opts) for _ in range(in_flight)]
+        for q in gs:
+            q.set_trace_mode(args.trace_mode)
+            if args.sweeps_in_turn:
+                q.set_option("sweeps_in_turn", 1)
+            if args.kernel_timing:
+                q.set_option("kernel_timing", 1)
     else:
         from oracle.rt_oracle import Oracle
-        g = Oracle(wl["width"], wl["height"], threads=max(1, (os.cpu_count() or 2) // max(world, 1)))
-    setup_scene(g, wl)
+        gs = [Oracle(wl["width"], wl["height"], threads=max(1, (os.cpu_count() or 2) // max(world, 1)))]
+    for q in gs:
+        setup_scene(q, wl)
+    g = gs[0]
     mode = args.sharding
     if mode == "auto":
         mode = "tiles" if wl["kind"] == "tiles" else "batch"
     scaling = "strong"
-    if wl["kind"] == "tiles" and (world == 1 or mode == "tiles"):
-        job = sharding.TileShardedFrame(g, wl["width"], wl["height"], shard_dev, bind_device_framebuffer=on_gpu)
+
+    def make_job(renderers):
+        if wl["kind"] == "tiles" and (world == 1 or mode == "tiles"):
+            return sharding.TileShardedFrame(renderers, wl["width"], wl["height"], shard_dev, bind_device_framebuffer=on_gpu)
+        # whole frames: one frame of a single-frame workload per rank per step, or the workload's views dealt out
+        cams = wl["cams"] * world if wl["kind"] == "tiles" else wl["cams"]
+        return sharding.FrameBatch(renderers, wl["width"], wl["height"], cams, shard_dev, bind_device_framebuffer=on_gpu)
+
+    job = make_job(gs)
+    if isinstance(job, sharding.TileShardedFrame):
         shard_desc = f"image tiles of {job.tile_rows} rows, interleaved over {world} rank(s), gathered to rank 0"
     elif wl["kind"] == "tiles":
-        # one whole frame of the workload per rank per step
-        job = sharding.FrameBatch(g, wl["width"], wl["height"], wl["cams"] * world, shard_dev, bind_device_framebuffer=on_gpu)
         shard_desc = f"frame batch: {world} frames per step, one per rank, gathered to rank 0"
         scaling = "weak"
     else:
-        job = sharding.FrameBatch(g, wl["width"], wl["height"], wl["cams"], shard_dev, bind_device_framebuffer=on_gpu)
         shard_desc = f"frame batch: view k on rank k % {world}, frames gathered to rank 0"
+    if in_flight > 1:
+        shard_desc += (f"; {in_flight} frames in flight per GPU (contexts that take the frames in turn, each on its own stream)"
+                       if isinstance(job, sharding.TileShardedFrame) else
+                       f"; {in_flight} views in flight per GPU (contexts that take a rank's views in turn, each on its own stream)")
 
     def sync_all():
         if on_gpu:
-            g.sync()
+            for q in gs:
+                q.sync()
             torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
             if on_gpu:
                 torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
+    # (every context in flight renders at least one untimed frame)
+    for _ in range(max(args.warmup, in_flight if isinstance(job, sharding.TileShardedFrame) else 0)):
         job.render(wl["passes"])
     sync_all()
     if on_gpu:
-        g.counters()
-        g.kernel_log()
-        g.stage_ms()
+        for q in gs:
+            q.counters()
+            q.kernel_log()
+            q.stage_ms()
 
     frame = None
     t0 = time.perf_counter()
@@ -391,9 +427,12 @@ def main():
         frame_crc = "%08x" % zlib.crc32(frame.contiguous().cpu().numpy().tobytes())
 
     if on_gpu:
-        cnt = g.counters()
-        log = g.kernel_log()
-        stage_ms = g.stage_ms()
+        cnt, log, stage_ms = {}, [], [0.0, 0.0, 0.0]
+        for q in gs:
+            for k, v in q.counters().items():
+                cnt[k] = cnt.get(k, 0) + v
+            log.extend(q.kernel_log())
+            stage_ms = [a + b for a, b in zip(stage_ms, q.stage_ms())]
     else:
         # the stand-in renderer counts nothing: rays = pixels rendered
         n_px = float(getattr(g, "num_rays", wl["width"] * wl["height"])) * len(getattr(job, "mine", [0])) * args.steps
@@ -414,14 +453,15 @@ def main():
         steps = max(args.steps, 1)
         rays = tot[0] + tot[1]
         # traversal launches of the timed region on rank 0, by kernel (a side-by-side bounce pass is one
-        # record for its two kernels)
+        # record for its kernels); untimed -- an event pair around every launch costs the stream idle
+        # time -- unless --kernel-timing asks for it (the kernels are timed one by one after the region)
         groups = {}
         for name, r in named_launches(log, args.sweeps_in_turn):
             a = groups.setdefault(name, dict(ms=0.0, launches=0, pairs=0.0))
             a["ms"] += float(r["ms"]); a["pairs"] += float(r["pairs"]); a["launches"] += 1
-        kernels = [dict(kernel=k, launches=a["launches"], avg_ms=a["ms"] / a["launches"], total_ms=a["ms"],
-                        pairs_per_launch=a["pairs"] / a["launches"])
-                   for k, a in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])]
+        kernels = [dict(kernel=k, launches=a["launches"], pairs_per_launch=a["pairs"] / a["launches"],
+                        **(dict(avg_ms=a["ms"] / a["launches"], total_ms=a["ms"]) if args.kernel_timing else {}))
+                   for k, a in sorted(groups.items(), key=lambda kv: (-kv[1]["ms"], -kv[1]["launches"]))]
         views = len(getattr(job, "cameras", wl["cams"]))
         out = {
             "metric": METRIC, "value": rays / dt / 1e6, "unit": "Mrays/s", "n_gpus": world,
@@ -432,6 +472,7 @@ def main():
                        "height": wl["height"], "views": views, "triangles": int(wl["mesh"].shape[0] // 3),
                        "passes": wl["passes"], "lights": wl["lights"], "sharding": shard_desc,
                        "trace_mode": ("filtered", "exact", "clustered")[args.trace_mode], "options": args.opt,
+                       "frames_in_flight": in_flight,
                        "rays_per_step": rays / steps,
                        "closest_hit_rays_per_step": tot[0] / steps, "shadow_rays_per_step": tot[1] / steps,
                        # the reference traces a shadow ray per light for every pixel in every pass, dead
@@ -442,11 +483,29 @@ def main():
                        "frame_crc32": frame_crc},
             # what the brute-force loop would have to sustain to decide the same pairs in the same time
             "equivalent_bruteforce_tflops": (tot[2] + tot[3]) * FLOP_PER_TEST / dt / 1e12,
+            # (summed over the contexts in flight, whose stages overlap: more than the step's wall time then)
             "stage_ms_per_step_rank0": {"raygen": stage_ms[0] / steps, "intersect": stage_ms[1] / steps,
                                         "color": stage_ms[2] / steps},
             "roofline": None,
             "kernels_rank0": kernels[:6],
         }
+        solo = None
+        if on_gpu and world == 1 and in_flight > 1:
+            # the kernels are timed on one context with nothing beside it
+            solo = make_job(g)
+            for _ in range(2):
+                solo.render(wl["passes"])
+            sync_all()
+            g.counters(); g.kernel_log(); g.stage_ms()
+            solo_steps = 3
+            for _ in range(solo_steps):
+                solo.render(wl["passes"])
+            sync_all()
+            stage_ms = g.stage_ms()
+            g.counters(); g.kernel_log()
+            out["stage_ms_per_step_one_frame_at_a_time"] = {"raygen": stage_ms[0] / solo_steps, "intersect": stage_ms[1] / solo_steps,
+                                                            "color": stage_ms[2] / solo_steps}
+            steps = solo_steps
         if on_gpu and stage_ms[0] > 0:
             # raygen: 14 planes of one float written per ray, nothing read
             frames = max(1, len(getattr(job, "mine", [0])))  # raygen launches per step on this rank
@@ -457,6 +516,7 @@ def main():
                                       "avg_launch_ms": stage_ms[0] / (steps * frames),
                                       "bytes_per_launch": RAY_PLANE_BYTES * g.num_rays}
         if on_gpu and world == 1 and args.trace_mode == 2 and not args.no_kernel_rooflines:
+            job = solo or job
             per_kernel = kernel_rooflines(g, job, wl, args.workload)
             if per_kernel:
                 dom = dict(per_kernel[0])
@@ -475,7 +535,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if on_gpu:
-        g.close()
+        for q in gs:
+            q.close()
 
 
 if __name__ == "__main__":

@@ -163,6 +163,10 @@ int rt_set_trace_mode(rt_ctx *ctx, int mode /* rt_trace_mode */);
  *                           origin are when its previous lists served a single launch before it moved
  *                           and the frame has fewer than 16 rays per triangle: coarser lists are
  *                           built faster and read slower
+ *   RT_OPT_KERNEL_TIMING    1: every traversal launch is bracketed by a hipEvent pair and rt_kernel_log
+ *                           reports its duration; 0 (default): the log's records carry ms = 0.  An event
+ *                           between two kernels costs the stream about 5 us of idle time, which a frame
+ *                           of some thirty traversal launches should not pay unasked
  * RT_OPT_GRID_BITS, RT_OPT_BAND_LIST_MAX and RT_OPT_VOXEL_RES decide what rt_set_mesh builds: after
  * setting one of them the context has no mesh until the next rt_set_mesh. */
 typedef enum rt_option {
@@ -174,7 +178,8 @@ typedef enum rt_option {
     RT_OPT_VOXEL_RES        = 5,
     RT_OPT_WALK_BUDGET      = 6,
     RT_OPT_FAIL_NEXT_STAGE  = 7,
-    RT_OPT_MOVING_ORIGIN_LEVELS = 8
+    RT_OPT_MOVING_ORIGIN_LEVELS = 8,
+    RT_OPT_KERNEL_TIMING    = 9
 } rt_option;
 int rt_set_option(rt_ctx *ctx, int option /* rt_option */, long long value);
 
@@ -221,7 +226,8 @@ int rt_read_depth(rt_ctx *ctx, float *out);
 /* Milliseconds spent in each stage {raygen, intersect, color} by the stage
  * calls since the last rt_stage_ms / rt_create, measured with hipEvent pairs on
  * the context's stream (replaces OpenGLTimer.cpp:18-41; float, not truncated).
- * Synchronises. */
+ * Inside rt_render one event ends a stage and begins the next, so the three
+ * numbers of a frame add up to the frame.  Synchronises. */
 int rt_stage_ms(rt_ctx *ctx, float ms[3]);
 
 /* Work counters of the stage calls since the last rt_get_counters / rt_create.
@@ -251,7 +257,8 @@ int rt_get_counters(rt_ctx *ctx, uint64_t counters[8]);
  *   rays  : rays the launch traversed
  *   pairs : (ray, triangle) pairs = rays x triangles (x lights for stage 2; an
  *           upper bound there, early exit may stop sooner)
- *   ms    : duration of that one launch, from a hipEvent pair around it
+ *   ms    : duration of that one launch, from a hipEvent pair around it (0 unless
+ *           RT_OPT_KERNEL_TIMING was 1 when it was launched)
  * Writes at most `max` records, returns the number written in *n.  Synchronises. */
 typedef struct rt_kernel_record {
     int32_t  stage;
@@ -270,7 +277,11 @@ int rt_kernel_log(rt_ctx *ctx, rt_kernel_record *out, int max, int *n);
  * call enqueue on `hip_stream` (a hipStream_t; NULL is HIP's default stream);
  * rt_unbind_stream returns to the context's own stream.  `device_rgba8` must
  * hold rt_local_rows() * width * 4 bytes on the context's device; NULL returns
- * to the context's own framebuffer.  All three synchronise the stream in use. */
+ * to the context's own framebuffer.  The two stream calls synchronise the stream
+ * in use.  rt_bind_framebuffer does not wait: stage calls enqueued before it keep
+ * writing to the framebuffer they were enqueued with, which the caller keeps
+ * alive until they have finished (a batch of views into one tensor is enqueued
+ * without a wait between views). */
 int rt_bind_stream(rt_ctx *ctx, void *hip_stream);
 int rt_unbind_stream(rt_ctx *ctx);
 int rt_bind_framebuffer(rt_ctx *ctx, void *device_rgba8);

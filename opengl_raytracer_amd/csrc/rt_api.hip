@@ -198,14 +198,21 @@ struct rt_ctx {
     unsigned long long *sum_h = nullptr; // pinned
 
     float acc_ms[3] = {0, 0, 0};
-    std::vector<EventPair> ev_pool;
-    std::vector<std::pair<int, int>> ev_used; // (stage, pool index)
+    // stage timing: a pool of events; a stage call is timed from one event to another, and inside
+    // rt_render the event that ends a stage also begins the next (an event between two kernels costs
+    // the stream about 5 us of idle time, a frame of six passes has 13 stage calls)
+    struct StageSpan { int stage, a, b; };
+    std::vector<hipEvent_t> ev_pool;
+    std::vector<StageSpan> ev_used;
     size_t ev_next = 0;
+    bool chain_stage_events = false; // set by rt_render: the next stage call begins where the last one ended
+    bool kernel_timing = false;      // RT_OPT_KERNEL_TIMING: event pairs around the traversal launches
     // kernel log: a ring of event pairs around the traversal launches
     static constexpr int KLOG = 1024;
     EventPair klog_ev[KLOG] = {};
     rt_kernel_record klog_rec[KLOG] = {}; // until read: rays = the count if known on the host, pairs = triangles per ray
     int klog_nslot[KLOG] = {};            // entry of klog_n_d that holds the launch's ray count, or -1
+    bool klog_timed[KLOG] = {};           // the record's event pair was recorded (kernel_timing at its launch)
     int *klog_n_d = nullptr;              // list lengths, written by the stages' setup kernels
     int n_slot_next = 0;
     size_t klog_count = 0; // launches logged since the last read
@@ -450,10 +457,7 @@ extern "C" void rt_destroy(rt_ctx *c)
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->stream_side) (void)hipStreamDestroy(c->stream_side);
-    for (auto &p : c->ev_pool) {
-        (void)hipEventDestroy(p.a);
-        (void)hipEventDestroy(p.b);
-    }
+    for (auto &e : c->ev_pool) (void)hipEventDestroy(e);
     for (int i = 0; i < rt_ctx::KLOG; i++) {
         if (c->klog_ev[i].a) (void)hipEventDestroy(c->klog_ev[i].a);
         if (c->klog_ev[i].b) (void)hipEventDestroy(c->klog_ev[i].b);
@@ -833,6 +837,10 @@ extern "C" int rt_set_option(rt_ctx *c, int option, long long value)
         if (value < 0 || value > 4) break;
         c->moving_origin_levels = (int)value;
         return RT_OK;
+    case RT_OPT_KERNEL_TIMING:
+        if (value != 0 && value != 1) break;
+        c->kernel_timing = value != 0;
+        return RT_OK;
     case RT_OPT_WALK_BUDGET:
         if (value < 0 || value > (1 << 24)) break;
         c->walk_budget = (int)value;
@@ -866,32 +874,46 @@ static int fold_events(rt_ctx *c)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (auto &u : c->ev_used) {
         float t = 0.0f;
-        HIPCHK(c, hipEventElapsedTime(&t, c->ev_pool[u.second].a, c->ev_pool[u.second].b));
-        c->acc_ms[u.first] += t;
+        HIPCHK(c, hipEventElapsedTime(&t, c->ev_pool[u.a], c->ev_pool[u.b]));
+        c->acc_ms[u.stage] += t;
     }
     c->ev_used.clear();
     c->ev_next = 0;
     return RT_OK;
 }
 
+static int take_event(rt_ctx *c, int *idx)
+{
+    if (c->ev_next == c->ev_pool.size()) {
+        hipEvent_t e;
+        HIPCHK(c, hipEventCreate(&e));
+        c->ev_pool.push_back(e);
+    }
+    *idx = (int)c->ev_next++;
+    return RT_OK;
+}
+// (slot: the entry of ev_used; its end event is recorded by stage_end or by StageScope)
 static int stage_begin(rt_ctx *c, int stage, size_t *slot)
 {
-    if (c->ev_next >= 1024)
+    const bool chain = c->chain_stage_events && !c->ev_used.empty();
+    c->chain_stage_events = false;
+    if (c->ev_next >= 2048 && !chain)
         if (int r = fold_events(c)) return r;
-    if (c->ev_next == c->ev_pool.size()) {
-        EventPair p;
-        HIPCHK(c, hipEventCreate(&p.a));
-        HIPCHK(c, hipEventCreate(&p.b));
-        c->ev_pool.push_back(p);
+    rt_ctx::StageSpan sp{stage, 0, 0};
+    if (chain && !c->ev_used.empty()) {
+        sp.a = c->ev_used.back().b; // where the stage call before this one ended
+    } else {
+        if (int r = take_event(c, &sp.a)) return r;
+        HIPCHK(c, hipEventRecord(c->ev_pool[sp.a], c->stream));
     }
-    *slot = c->ev_next++;
-    c->ev_used.push_back({stage, (int)*slot});
-    HIPCHK(c, hipEventRecord(c->ev_pool[*slot].a, c->stream));
+    if (int r = take_event(c, &sp.b)) return r;
+    *slot = c->ev_used.size();
+    c->ev_used.push_back(sp);
     return RT_OK;
 }
 static int stage_end(rt_ctx *c, size_t slot)
 {
-    HIPCHK(c, hipEventRecord(c->ev_pool[slot].b, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev_pool[c->ev_used[slot].b], c->stream));
     return RT_OK;
 }
 
@@ -992,12 +1014,13 @@ static int klog_begin(rt_ctx *c, int stage, int form, int k, bool exact, int n_s
     r.rays = fixed_rays; r.pairs = tris; r.ms = 0.0f; r.reserved = 0.0f;
     c->klog_nslot[*slot] = n_slot;
     c->klog_count++;
-    HIPCHK(c, hipEventRecord(c->klog_ev[*slot].a, c->stream));
+    c->klog_timed[*slot] = c->kernel_timing;
+    if (c->kernel_timing) HIPCHK(c, hipEventRecord(c->klog_ev[*slot].a, c->stream));
     return RT_OK;
 }
 static int klog_end(rt_ctx *c, size_t slot)
 {
-    HIPCHK(c, hipEventRecord(c->klog_ev[slot].b, c->stream));
+    if (c->klog_timed[slot]) HIPCHK(c, hipEventRecord(c->klog_ev[slot].b, c->stream));
     return RT_OK;
 }
 // the entry of klog_n_d the next setup kernel writes its list's length to
@@ -1400,7 +1423,7 @@ struct StageScope {
     bool open = false;
     ~StageScope()
     {
-        if (open) (void)hipEventRecord(c->ev_pool[slot].b, c->stream);
+        if (open) (void)hipEventRecord(c->ev_pool[c->ev_used[slot].b], c->stream);
     }
 };
 
@@ -1644,9 +1667,12 @@ extern "C" int rt_render(rt_ctx *c, int passes)
     if (passes < 1) return fail(c, RT_ERR_ARG, "rt_render: passes=%d must be >= 1", passes);
     if (int r = rt_raygen(c)) return r;
     for (int pss = 0; pss < passes; pss++) {
+        c->chain_stage_events = true;
         if (int r = rt_intersect(c)) return r;
+        c->chain_stage_events = true;
         if (int r = rt_color(c)) return r;
     }
+    c->chain_stage_events = false;
     return RT_OK;
 }
 
@@ -1767,8 +1793,10 @@ extern "C" int rt_kernel_log(rt_ctx *c, rt_kernel_record *out, int max, int *n)
         rt_kernel_record r = c->klog_rec[slot];
         if (c->klog_nslot[slot] >= 0) r.rays = (unsigned long long)n_h[c->klog_nslot[slot]];
         r.pairs = r.rays * r.pairs; // triangles per ray until now
-        // (a launch that failed half-way left its record open: reported with 0 ms)
-        if (hipEventElapsedTime(&r.ms, c->klog_ev[slot].a, c->klog_ev[slot].b) != hipSuccess) {
+        // (a launch that failed half-way left its record open: reported with 0 ms; so is an untimed one)
+        if (!c->klog_timed[slot]) {
+            r.ms = 0.0f;
+        } else if (hipEventElapsedTime(&r.ms, c->klog_ev[slot].a, c->klog_ev[slot].b) != hipSuccess) {
             (void)hipGetLastError();
             r.ms = 0.0f;
         }
@@ -1801,7 +1829,7 @@ extern "C" int rt_bind_framebuffer(rt_ctx *c, void *device_rgba8)
 {
     if (!c) return RT_ERR_ARG;
     if (int r = use_device(c)) return r;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // (no wait: the kernels already enqueued hold the pointer they were launched with)
     c->fb = device_rgba8 ? reinterpret_cast<uint32_t *>(device_rgba8) : c->fb_own;
     c->chunk_filed_valid[1] = false; // the new framebuffer has not seen the grey pixels of skipped chunks
     return RT_OK;

@@ -10,6 +10,12 @@ Two shardings, both of independent units:
 The renderer is whatever object has the RayTracer surface (set_row_tiles, row_map,
 render, ...).  How its pixels reach a torch tensor: on the GPU the
 tensor is bound as the context's framebuffer (no copy), elsewhere pixels are copied.
+
+Frames in flight: a frame is a chain of some hundred dependent kernels, and a rank's share of
+a frame leaves most of a GPU idle between them.  Both classes therefore accept a LIST of renderers
+(contexts with the same scene): consecutive frames (or views) go to them in turn, each on a stream
+of its own, so that the chains of consecutive frames overlap on the GPU.  A frame returned by
+render() is complete once its stream has been waited for (`wait()` does that for all of them).
 """
 import numpy as np
 import torch
@@ -40,57 +46,107 @@ def _world():
     return 0, 1
 
 
+def _as_list(renderers):
+    return list(renderers) if isinstance(renderers, (list, tuple)) else [renderers]
+
+
+class _Streams:
+    """The streams of renderers that run on the GPU with bound framebuffers: a single renderer works on
+    the stream that is current when the object is made; several get a stream of their own each (none of
+    them HIP's default stream, which does not run beside the others)."""
+
+    def __init__(self, renderers, device, bound):
+        self.device, self.bound = device, bound
+        self.streams = []
+        if bound:
+            cur = torch.cuda.current_stream(device)
+            self.streams = [cur] if len(renderers) == 1 else [torch.cuda.Stream(device) for _ in renderers]
+            for r, s in zip(renderers, self.streams):
+                if s != cur:
+                    s.wait_stream(cur)
+                r.bind_stream(s.cuda_stream)
+
+    def on(self, i):
+        import contextlib
+        return torch.cuda.stream(self.streams[i]) if self.bound else contextlib.nullcontext()
+
+    def wait(self):
+        """The stream that is current waits for every renderer's stream."""
+        if self.bound:
+            cur = torch.cuda.current_stream(self.device)
+            for s in self.streams:
+                if s != cur:
+                    cur.wait_stream(s)
+
+
 class TileShardedFrame:
-    """One frame cut into interleaved row tiles over the ranks of the default process group."""
+    """One frame cut into interleaved row tiles over the ranks of the default process group.
+    `renderer`: one renderer, or a list of them for that many frames in flight."""
 
     def __init__(self, renderer, width, height, device, tile_rows=None, bind_device_framebuffer=True):
-        self.r = renderer
+        self.rs = _as_list(renderer)
+        self.r = self.rs[0]
         self.width, self.height = int(width), int(height)
         self.device = torch.device(device)
         self.rank, self.world = _world()
         self.tile_rows = tile_rows or choose_tile_rows(self.height, self.world)
-        self.r.set_row_tiles(self.tile_rows, self.rank, self.world)
+        for r in self.rs:
+            r.set_row_tiles(self.tile_rows, self.rank, self.world)
         self.rows = np.asarray(self.r.row_map(), dtype=np.int64)
         assert np.array_equal(self.rows, tile_rows_of_rank(self.height, self.tile_rows, self.rank, self.world))
         # every rank's slab is padded to the largest one so that the gather is uniform
         self.max_rows = max(tile_rows_of_rank(self.height, self.tile_rows, q, self.world).shape[0]
                             for q in range(self.world))
-        self.local = torch.zeros((self.max_rows, self.width, 4), dtype=torch.uint8, device=self.device)
         self.bound = bool(bind_device_framebuffer and self.device.type == "cuda")
+        assert self.bound or len(self.rs) == 1, "frames in flight need device framebuffers"
+        # per renderer: its slab, and on rank 0 the gathered slabs and the assembled frame
+        self.locals = [torch.zeros((self.max_rows, self.width, 4), dtype=torch.uint8, device=self.device) for _ in self.rs]
+        self.local = self.locals[0]
+        self.streams = _Streams(self.rs, self.device, self.bound)
         if self.bound:
-            self.r.bind_stream(torch.cuda.current_stream(self.device).cuda_stream)
-            self.r.bind_framebuffer(self.local.data_ptr())
+            for r, loc in zip(self.rs, self.locals):
+                r.bind_framebuffer(loc.data_ptr())
         if self.rank == 0:
-            self.gathered = [torch.zeros_like(self.local) for _ in range(self.world)]
+            self.gathered = [[torch.zeros_like(self.local) for _ in range(self.world)] for _ in self.rs]
             # frame row -> position in the concatenated slabs
             perm = np.zeros(self.height, dtype=np.int64)
             for q in range(self.world):
                 rows_q = tile_rows_of_rank(self.height, self.tile_rows, q, self.world)
                 perm[rows_q] = q * self.max_rows + np.arange(rows_q.shape[0])
             self.perm = torch.from_numpy(perm).to(self.device)
-            self.frame = torch.zeros((self.height, self.width, 4), dtype=torch.uint8, device=self.device)
+            self.frames = [torch.zeros((self.height, self.width, 4), dtype=torch.uint8, device=self.device) for _ in self.rs]
+        self.turn = 0
 
     def render(self, passes):
-        """Renders this rank's tiles and gathers the frame on rank 0 (returns it there, else None)."""
-        self.r.render(passes)
-        if not self.bound:
-            px = torch.from_numpy(np.ascontiguousarray(self.r.read_pixels()))
-            self.local[: px.shape[0]].copy_(px)
-        if self.world == 1:
-            return self.local[: self.height]  # one rank owns every tile, rows already in order
-        dist.gather(self.local, self.gathered if self.rank == 0 else None, dst=0)
-        if self.rank != 0:
-            return None
-        slabs = torch.cat(self.gathered, dim=0)
-        torch.index_select(slabs, 0, self.perm, out=self.frame)
-        return self.frame
+        """Renders this rank's tiles and gathers the frame on rank 0 (returns it there, else None).
+        With several renderers the frame is complete once wait() (or a device synchronize) has returned."""
+        i = self.turn
+        self.turn = (self.turn + 1) % len(self.rs)
+        r, local = self.rs[i], self.locals[i]
+        with self.streams.on(i):
+            r.render(passes)
+            if not self.bound:
+                px = torch.from_numpy(np.ascontiguousarray(r.read_pixels()))
+                local[: px.shape[0]].copy_(px)
+            if self.world == 1:
+                return local[: self.height]  # one rank owns every tile, rows already in order
+            dist.gather(local, self.gathered[i] if self.rank == 0 else None, dst=0)
+            if self.rank != 0:
+                return None
+            slabs = torch.cat(self.gathered[i], dim=0)
+            torch.index_select(slabs, 0, self.perm, out=self.frames[i])
+            return self.frames[i]
+
+    def wait(self):
+        self.streams.wait()
 
 
 class FrameBatch:
     """A batch of camera views, view k rendered by rank k % world; frames gathered to rank 0."""
 
     def __init__(self, renderer, width, height, cameras, device, bind_device_framebuffer=True):
-        self.r = renderer
+        self.rs = _as_list(renderer)
+        self.r = self.rs[0]
         self.width, self.height = int(width), int(height)
         self.device = torch.device(device)
         self.rank, self.world = _world()
@@ -99,22 +155,28 @@ class FrameBatch:
         self.max_views = (len(self.cameras) + self.world - 1) // self.world
         self.local = torch.zeros((self.max_views, self.height, self.width, 4), dtype=torch.uint8, device=self.device)
         self.bound = bool(bind_device_framebuffer and self.device.type == "cuda")
-        if self.bound:
-            self.r.bind_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        assert self.bound or len(self.rs) == 1, "views in flight need device framebuffers"
+        self.streams = _Streams(self.rs, self.device, self.bound)
         if self.rank == 0:
             self.gathered = [torch.zeros_like(self.local) for _ in range(self.world)]
 
     def render(self, passes):
+        # this rank's views go to the renderers in turn (a renderer's next view waits for its last one only)
         for j, k in enumerate(self.mine):
-            self.r.set_camera(*self.cameras[k])
-            if self.bound:
-                self.r.bind_framebuffer(self.local[j].data_ptr())
-                self.r.render(passes)
-            else:
-                self.r.render(passes)
-                self.local[j].copy_(torch.from_numpy(np.ascontiguousarray(self.r.read_pixels())))
+            i = j % len(self.rs)
+            r = self.rs[i]
+            with self.streams.on(i):
+                r.set_camera(*self.cameras[k])
+                if self.bound:
+                    r.bind_framebuffer(self.local[j].data_ptr())
+                    r.render(passes)
+                else:
+                    r.render(passes)
+                    self.local[j].copy_(torch.from_numpy(np.ascontiguousarray(r.read_pixels())))
         if self.bound:
-            self.r.bind_framebuffer(0)
+            for r in self.rs:
+                r.bind_framebuffer(0)
+            self.streams.wait()
         if self.world == 1:
             return self.local[: len(self.cameras)]
         dist.gather(self.local, self.gathered if self.rank == 0 else None, dst=0)
@@ -123,3 +185,6 @@ class FrameBatch:
         # view k sits at slab k % world, slot k // world
         stacked = torch.stack(self.gathered, dim=1).reshape(-1, self.height, self.width, 4)
         return stacked[: len(self.cameras)]
+
+    def wait(self):
+        self.streams.wait()

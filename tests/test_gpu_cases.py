@@ -429,3 +429,64 @@ def test_framebuffer_bound_between_passes_gets_every_pixel(rt, oracle_mod):
         assert np.array_equal(late.cpu().numpy(), c.read_pixels())
         same("rays", g, c, pixels=False)
         g.bind_framebuffer(0)
+
+
+# -- frames in flight ---------------------------------------------------------------------------------
+def test_views_in_flight_on_two_contexts_against_oracle(rt, oracle_mod):
+    """Five views dealt to two contexts in turn, each context on a stream of its own and writing
+    into its slice of one device tensor with no wait between views (sharding.FrameBatch with a list
+    of renderers): every frame equals the oracle's, whatever overlapped with it."""
+    import torch
+    from opengl_raytracer_amd import scenes, sharding
+    sc = small_scene("mixed")
+    w, h, passes = 160, 96, 3
+    cams = [scenes.look_at_camera((2.6 * np.cos(a), 0.4, 2.6 * np.sin(a)), (0, 0, 0)) for a in (0.3, 1.1, 2.0, 3.3, 4.9)]
+    dev = torch.device("cuda", 0)
+    gs = [rt.RayTracer(w, h, options={"sort_min_rays": 1024}) for _ in range(2)]
+    c = oracle_mod.Oracle(w, h, threads=8)
+    try:
+        for o in gs + [c]:
+            setup(o, sc, 2)
+        job = sharding.FrameBatch(gs, w, h, cams, dev)
+        for _ in range(2):   # the second batch finds the contexts' lists and counters as the first left them
+            frames = job.render(passes)
+            job.wait()
+            torch.cuda.synchronize(dev)
+            frames = frames.cpu().numpy()
+            for j, cam in enumerate(cams):
+                c.set_camera(*cam)
+                c.render(passes)
+                assert np.array_equal(frames[j], c.read_pixels()), f"view {j}: pixels differ"
+        # view 4 was the third view of context 0: its rays are still there
+        same("last view of context 0", gs[0], c, pixels=False)
+    finally:
+        for g in gs:
+            g.close()
+
+
+def test_frames_in_flight_tiles_on_three_contexts(rt, oracle_mod):
+    """sharding.TileShardedFrame with three renderers: consecutive frames go to the contexts in turn
+    (streams of their own, framebuffers bound); every frame returned equals the oracle's frame."""
+    import torch
+    from opengl_raytracer_amd import sharding
+    sc = small_scene("mixed")
+    w, h, passes = 128, 80, 3
+    dev = torch.device("cuda", 0)
+    gs = [rt.RayTracer(w, h, options={"sort_min_rays": 1024}) for _ in range(3)]
+    c = oracle_mod.Oracle(w, h, threads=8)
+    try:
+        for o in gs + [c]:
+            setup(o, sc, 2)
+        c.render(passes)
+        want = c.read_pixels()
+        job = sharding.TileShardedFrame(gs, w, h, dev)
+        frames = [job.render(passes) for _ in range(7)]
+        job.wait()
+        torch.cuda.synchronize(dev)
+        for k in (4, 5, 6):   # the last frame of each context
+            assert np.array_equal(frames[k].cpu().numpy(), want), f"frame {k}: pixels differ"
+        for g in gs:
+            same("context", g, c, pixels=False)
+    finally:
+        for g in gs:
+            g.close()

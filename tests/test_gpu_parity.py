@@ -357,10 +357,25 @@ def test_stage_timers_and_counters(rt):
     with rt.RayTracer(256, 256) as g:
         setup(g, sc, 1)
         g.stage_ms()
+        # untimed by default: records without durations
+        g.render(2)
+        assert (g.kernel_log()["ms"] == 0).all()
+        g.stage_ms()
+        g.set_option("kernel_timing", 1)
         g.render(2)
         ms = g.stage_ms()
         assert all(m > 0 for m in ms)
         assert g.stage_ms() == [0.0, 0.0, 0.0]
+        # the stage calls of rt_render are timed end to end: a frame's stages add up to the frame
+        g.sync()
+        import time
+        t0 = time.perf_counter()
+        g.render(2)
+        g.sync()
+        wall = (time.perf_counter() - t0) * 1e3
+        assert sum(g.stage_ms()) <= wall * 1.05 + 0.05
+        g.kernel_log()
+        g.render(2)
         log = g.kernel_log()
         # fresh rays share the camera origin (direction cells), shadow rays the light; bounce rays: clustered,
         # one record for the band sweep and the walk over cells running side by side (three records when they

@@ -9,6 +9,7 @@ name = sys.argv[1] if len(sys.argv) > 1 else "soup64k_4k_p6"
 wl = workload(name)
 # RT_DIAG_OPTS="voxel_res=32,sweeps_in_turn=1": options of the context (rt_set_option)
 opts = dict((k, int(v)) for k, v in (kv.split("=") for kv in os.environ.get("RT_DIAG_OPTS", "").split(",") if kv))
+opts.setdefault("kernel_timing", 1)
 g = rt.RayTracer(wl["width"], wl["height"], options=opts)
 setup_scene(g, wl)
 if os.environ.get("RT_DIAG_WORLD"):  # one rank's share of the frame (interleaved tiles of 16 rows)

@@ -12,7 +12,7 @@ from bench import workload, setup_scene
 wl = workload(sys.argv[1] if len(sys.argv) > 1 else "soup64k_4k_p6")
 base = None
 for world in [int(x) for x in os.environ.get('WORLDS', '1,2,4,8').split(',')]:
-    g = rt.RayTracer(wl["width"], wl["height"])
+    g = rt.RayTracer(wl["width"], wl["height"], options={"kernel_timing": int(os.environ.get("KERNEL_TIMING", "0"))})
     setup_scene(g, wl)
     tr = int(os.environ.get('TILE_ROWS', '0')) or sharding.choose_tile_rows(wl["height"], world)
     g.set_row_tiles(tr, int(os.environ.get('RANK', world - 1)) % world, world)

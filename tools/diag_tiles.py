@@ -10,7 +10,9 @@ from bench import workload, setup_scene
 
 wl = workload(sys.argv[1] if len(sys.argv) > 1 else "soup64k_4k_p6")
 world = int(os.environ.get("WORLD", "8"))
-g = rt.RayTracer(wl["width"], wl["height"])
+# OPTS="walk_budget=24,voxel_res=32": options of the context (rt_set_option)
+opts = dict((k, int(v)) for k, v in (kv.split("=") for kv in os.environ.get("OPTS", "").split(",") if kv))
+g = rt.RayTracer(wl["width"], wl["height"], options=opts)
 setup_scene(g, wl)
 
 
@@ -33,7 +35,12 @@ if os.environ.get("ONLY_RANK"):
     g.close()
     sys.exit(0)
 base = share(wl["height"], 0, 1)
-print("whole frame %.2f ms" % base, flush=True)
+print("whole frame %.2f ms  %s" % (base, opts), flush=True)
+if os.environ.get("RANKS"):  # only these ranks' shares
+    tr = int(os.environ.get("TILE_ROWS", "15").split(",")[0])
+    print("world %d tile_rows %d:" % (world, tr), ["%.3f" % share(tr, int(r), world) for r in os.environ["RANKS"].split(",")], flush=True)
+    g.close()
+    sys.exit(0)
 for tr in [int(x) for x in os.environ.get("TILE_ROWS", "16,32,64,128").split(",")]:
     ms = [share(tr, r, world) for r in range(world)]
     print("world %d tile_rows %d: max %.2f mean %.2f ms -> speedup %.2fx  %s" %
