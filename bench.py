@@ -290,8 +290,8 @@ def spawn_ranks(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="soup64k_4k_p6")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-rooflines", action="store_true",
@@ -302,8 +302,9 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="contexts per GPU that take the frames (or views) of the sequence in turn, each on a stream "
                          "of its own, so that the kernel chains of consecutive frames overlap (1: one frame at a time; "
-                         "0: 2 for the single-frame workloads -- two contexts use the four hardware queues of a process "
-                         "-- and 3 for the view batch, whose single pass uses one stream per context)")
+                         "0: 3; with more than one, each context runs the two sweeps of a bounce pass in turn on its one "
+                         "stream instead of side by side on two -- the frames beside it fill the GPU, and a process has "
+                         "four hardware queues)")
     ap.add_argument("--kernel-timing", action="store_true",
                     help="event pairs around every traversal launch of the timed region too (for profiles)")
     ap.add_argument("--sharding", choices=("auto", "batch", "tiles"), default="auto",
@@ -350,7 +351,7 @@ def main():
 
     wl = workload(args.workload)
     # frames in flight need framebuffers on the device (pixels that go through the host are copied in turn)
-    in_flight = args.frames_in_flight if args.frames_in_flight > 0 else (2 if wl["kind"] == "tiles" else 3)
+    in_flight = args.frames_in_flight if args.frames_in_flight > 0 else 3
     if not (on_gpu and shard_dev.type == "cuda"):
         in_flight = 1
     if on_gpu:
@@ -359,7 +360,7 @@ def main():
         gs = [rt.RayTracer(wl["width"], wl["height"], device=local_rank, options=opts) for _ in range(in_flight)]
         for q in gs:
             q.set_trace_mode(args.trace_mode)
-            if args.sweeps_in_turn:
+            if args.sweeps_in_turn or in_flight > 1:
                 q.set_option("sweeps_in_turn", 1)
             if args.kernel_timing:
                 q.set_option("kernel_timing", 1)
@@ -456,7 +457,7 @@ def main():
         # record for its kernels); untimed -- an event pair around every launch costs the stream idle
         # time -- unless --kernel-timing asks for it (the kernels are timed one by one after the region)
         groups = {}
-        for name, r in named_launches(log, args.sweeps_in_turn):
+        for name, r in named_launches(log, args.sweeps_in_turn or in_flight > 1):
             a = groups.setdefault(name, dict(ms=0.0, launches=0, pairs=0.0))
             a["ms"] += float(r["ms"]); a["pairs"] += float(r["pairs"]); a["launches"] += 1
         kernels = [dict(kernel=k, launches=a["launches"], pairs_per_launch=a["pairs"] / a["launches"],
@@ -491,7 +492,8 @@ def main():
         }
         solo = None
         if on_gpu and world == 1 and in_flight > 1:
-            # the kernels are timed on one context with nothing beside it
+            # the kernels are timed on one context with nothing beside it (its sweeps side by side again)
+            g.set_option("sweeps_in_turn", 1 if args.sweeps_in_turn else 0)
             solo = make_job(g)
             for _ in range(2):
                 solo.render(wl["passes"])

@@ -16,9 +16,11 @@ rank = int(os.environ.get("RANK", "0"))
 ks = [int(x) for x in os.environ.get("INFLIGHT", "1,2,3").split(",")]
 frames = int(os.environ.get("FRAMES", "12"))
 
+# OPTS="sweeps_in_turn=1": options of the contexts (rt_set_option)
+opts = dict((k, int(v)) for k, v in (kv.split("=") for kv in os.environ.get("OPTS", "").split(",") if kv))
 ctxs = []
 for _ in range(max(ks)):
-    g = rt.RayTracer(wl["width"], wl["height"])
+    g = rt.RayTracer(wl["width"], wl["height"], options=opts)
     setup_scene(g, wl)
     ctxs.append(g)
 

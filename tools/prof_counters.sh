@@ -7,7 +7,7 @@ out=gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
 # the kernels of a bounce pass one after the other, so that every launch has a duration of its own
-cmd="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --sweeps-in-turn"
+cmd="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --sweeps-in-turn --frames-in-flight 1"
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- $cmd > $out/bench_trace.json 2> $out/trace.err || exit 1
 timeout -s KILL 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY --output-format csv -d $out/pmc_sq -o sq -- $cmd > $out/bench_sq.json 2> $out/sq.err || exit 2
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o f -- $cmd > $out/bench_f.json 2> $out/f.err || exit 3

@@ -17,7 +17,7 @@ def short(n):
 
 lines = []
 stats = list(csv.DictReader(open(f"{base}/trace/t_kernel_stats.csv")))
-lines.append("== rocprofv3 --kernel-trace --stats (python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --sweeps-in-turn) ==")
+lines.append("== rocprofv3 --kernel-trace --stats (python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --sweeps-in-turn --frames-in-flight 1) ==")
 traffic = {}
 lines.append(f"{'kernel':70s} {'calls':>6s} {'avg_us':>12s} {'total_ms':>10s} {'%':>6s}")
 for r in stats[:24]:
