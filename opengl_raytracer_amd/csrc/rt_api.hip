@@ -1558,43 +1558,57 @@ extern "C" int rt_color(rt_ctx *c)
             // (zero already when the last stage call to finish was an rt_intersect, whose last kernel saw to it)
             if (!c->count_clean[1]) HIPCHK(c, hipMemsetAsync(c->count_d + 1, 0, sizeof(int), c->stream));
             c->count_clean[1] = false;
+            // what an earlier first pass of this context counted (its last kernel stored the number in pinned host
+            // memory; nothing waits for it, so it may be a frame old, or -1: none yet)
+            const int seen_hits = *static_cast<volatile int *>(c->feedback_h);
+            const bool scattered = seen_hits >= 0 && 2ll * seen_hits < (long long)c->n_rays;
+            const int n0 = c->n_rays;
+            // in the clustered mode the shadow rays are visited in the order of the direction in
+            // which they leave the light (any order gives the same result); first-pass hits follow the
+            // pixels and are left in that order -- unless the last first pass saw hits on less than half
+            // of the frame: scattered objects rather than surfaces, whose hit points neighbouring pixels
+            // do not share (64 views of the 256K soup: shading 0.45 -> 0.28 ms per view)
+            const bool sorted = c->trace_mode == RT_TRACE_CLUSTERED && n0 >= c->sort_min_rays &&
+                                c->num_slots >= 8192 && !(use_grid(c) && c->hits_follow_pixels && !scattered);
             // the rays with a finite origin are filed under slots (and counted on the device; the host does not
-            // wait for it), each slot prepared for the loop over the lights by the thread that files it
+            // wait for it), each slot prepared by the thread that files it: for the loop over the lights, and
+            // with the shadow ray to the first light (shadow_setup_kernel's work for the other lights)
             CompactWork work{};
             work.scratch = c->scratch;
+            work.job = c->job;
+            work.so = shared_origin(c, c->lights[0].pos, -1.0f);
+            memcpy(work.light0, c->lights[0].pos, sizeof work.light0);
+            if (sorted) {
+                if (int r = bin_begin(c)) return r;
+                work.keys = c->sort_keys;
+                work.hist = c->bin_hist_d;
+            }
             hipLaunchKernelGGL((compact_kernel<1>), dim3(list_blocks(c->n_rays, BLOCK * COMPACT_ITERS)), dim3(BLOCK), 0,
                                c->stream, c->rays, (const int *)c->perm_d, (const int *)nullptr, (const int *)nullptr,
                                c->n_rays, (const int *)nullptr, c->list, c->count_d + 1, c->fb, work,
                                c->chunk_filed_d[1], c->chunk_filed_valid[1] ? 1 : 0);
             HIPCHK(c, hipGetLastError());
             c->chunk_filed_valid[1] = true;
-            const int n0 = c->n_rays;
             const int *cnt0 = c->count_d + 1;
             const dim3 g0(list_blocks(n0, BLOCK));
-            // what an earlier first pass of this context counted (its last kernel stored the number in pinned host
-            // memory; nothing waits for it, so it may be a frame old, or -1: none yet)
-            const int seen_hits = *static_cast<volatile int *>(c->feedback_h);
-            const bool scattered = seen_hits >= 0 && 2ll * seen_hits < (long long)c->n_rays;
+            int n_slot0 = -1;
             const bool exact = c->trace_mode == RT_TRACE_EXACT;
             const int n_trav = exact ? c->num_tris : c->num_slots; // slots, or triangles in the all-pairs mode
             const int chunk = shadow_chunk_tris(n_trav);
             for (int a = 0; a < c->num_lights; a++) {
-                // in the clustered mode the shadow rays are visited in the order of the direction in
-                // which they leave the light (any order gives the same result); first-pass hits follow the
-                // pixels and are left in that order -- unless the last first pass saw hits on less than half
-                // of the frame: scattered objects rather than surfaces, whose hit points neighbouring pixels
-                // do not share (64 views of the 256K soup: shading 0.45 -> 0.28 ms per view)
-                const bool sorted = c->trace_mode == RT_TRACE_CLUSTERED && n0 >= c->sort_min_rays &&
-                                    c->num_slots >= 8192 && !(use_grid(c) && c->hits_follow_pixels && !scattered);
                 const int n_slot = next_n_slot(c);
-                if (sorted)
-                    if (int r = bin_begin(c)) return r;
-                hipLaunchKernelGGL(shadow_setup_kernel, g0, dim3(BLOCK), 0, c->stream, cnt0, c->scratch, c->job,
-                                   c->lights[a].pos[0], c->lights[a].pos[1], c->lights[a].pos[2],
-                                   shared_origin(c, c->lights[a].pos, -1.0f), c->counters_d,
-                                   sorted ? c->sort_keys : (unsigned int *)nullptr,
-                                   sorted ? c->bin_hist_d : (unsigned int *)nullptr, c->klog_n_d + n_slot);
-                HIPCHK(c, hipGetLastError());
+                if (a == 0) {
+                    n_slot0 = n_slot; // (prepared by the compaction; color_finish_kernel notes their number)
+                } else {
+                    if (sorted)
+                        if (int r = bin_begin(c)) return r;
+                    hipLaunchKernelGGL(shadow_setup_kernel, g0, dim3(BLOCK), 0, c->stream, cnt0, c->scratch, c->job,
+                                       c->lights[a].pos[0], c->lights[a].pos[1], c->lights[a].pos[2],
+                                       shared_origin(c, c->lights[a].pos, -1.0f), c->counters_d,
+                                       sorted ? c->sort_keys : (unsigned int *)nullptr,
+                                       sorted ? c->bin_hist_d : (unsigned int *)nullptr, c->klog_n_d + n_slot);
+                    HIPCHK(c, hipGetLastError());
+                }
                 const int *alist = nullptr; // nullptr: slots 0..n-1
                 if (sorted) {
                     if (int r = bin_finish(c, c->sort_keys, cnt0, n0, ((size_t)1 << sort_key_bits(c)) + 1, c->sort_slots)) return r;
@@ -1644,13 +1658,19 @@ extern "C" int rt_color(rt_ctx *c)
                         pp ^= 1;
                     }
                 }
-                hipLaunchKernelGGL(shadow_finish_kernel, g0, dim3(BLOCK), 0, c->stream, c->rays,
-                                   (const int *)c->list, alist, acount, n0, c->scratch, c->job, c->lights[a], c->cam);
-                HIPCHK(c, hipGetLastError());
+                // (the last light's contribution is added by color_finish_kernel: slots whose ray is still
+                // unoccluded there are exactly the entries of alist)
+                if (a + 1 < c->num_lights) {
+                    hipLaunchKernelGGL(shadow_finish_kernel, g0, dim3(BLOCK), 0, c->stream, c->rays,
+                                       (const int *)c->list, alist, acount, n0, c->scratch, c->job, c->lights[a], c->cam);
+                    HIPCHK(c, hipGetLastError());
+                }
             }
             hipLaunchKernelGGL(color_finish_kernel, g0, dim3(BLOCK), 0, c->stream, c->rays, (const int *)c->list, cnt0,
                                c->scratch, c->verts, c->num_vertices, (const uint32_t *)c->tex, c->tex_w, c->tex_h,
-                               c->fb, c->count_d, c->hits_follow_pixels ? c->feedback_h : (int *)nullptr);
+                               c->fb, c->count_d, c->hits_follow_pixels ? c->feedback_h : (int *)nullptr, c->job,
+                               c->lights[c->num_lights - 1], c->cam, c->counters_d,
+                               n_slot0 >= 0 ? c->klog_n_d + n_slot0 : (int *)nullptr);
             HIPCHK(c, hipGetLastError());
             c->count_clean[0] = true;
         }

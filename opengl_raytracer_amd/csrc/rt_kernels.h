@@ -379,11 +379,46 @@ __global__ __launch_bounds__(BLOCK) void intersect_setup_kernel(RaySoA r, const 
 }
 
 // What rt_color prepares per slot of its list before the loop over the lights.
-__device__ __forceinline__ void color_begin_slot(const RaySoA &r, int i, int slot, const Scratch &s)
+// (the origin the loop over the lights mutates, s.so*, starts as the ray's: shadow_setup_slot of the first
+// light, called right after this with that origin, stores it as that light leaves it)
+__device__ __forceinline__ void color_begin_slot(int slot, const Scratch &s)
 {
-    s.sox[slot] = r.ox[i]; s.soy[slot] = r.oy[i]; s.soz[slot] = r.oz[i];
     s.lr[slot] = 0.0f; s.lg[slot] = 0.0f; s.lb[slot] = 0.0f;
     s.lit[slot] = 0;
+}
+
+// What rt_color prepares per slot for one light (raycol_cs.glsl:39-47): the shadow ray as the reference
+// forms it from the ray's origin `o` as the lights before this one left it, the origin as this light
+// leaves it, and what the shared-origin filters want; when the launch groups its rays by the direction
+// cell in which the light sees them (rt_grid.h), the slot's key, counted into hist[] here
+// (bin_count_kernel's work).  All lanes of a wavefront that are still in the caller's loop call this
+// together; `valid` says whether the lane has a slot.
+__device__ __forceinline__ void shadow_setup_slot(bool valid, int slot, v3 o, const Scratch &s, const Job &job,
+                                                  float lx, float ly, float lz, const SharedOrigin &so,
+                                                  unsigned int *keys, unsigned int *hist)
+{
+    unsigned int key = 0xffffffffu;
+    if (valid) {
+        const v3 lpos = rtx::V(lx, ly, lz);
+        const v3 ld = rtx::normalize(rtx::sub(lpos, o));
+        const v3 o2 = rtx::add(o, rtx::muls(ld, 0.0000001f)); // shadow-ray origin
+        o = rtx::sub(o, rtx::muls(ld, 0.0000001f));           // r.origin = r.origin - lightDir * 1e-7
+        s.sox[slot] = o.x; s.soy[slot] = o.y; s.soz[slot] = o.z;
+        const float dist = rtx::distance3(lpos, o);
+        job.ox[slot] = o2.x; job.oy[slot] = o2.y; job.oz[slot] = o2.z;
+        job.dx[slot] = ld.x; job.dy[slot] = ld.y; job.dz[slot] = ld.z;
+        job.tmax[slot] = dist;
+        s.occ[slot] = (dist < INFINITY) ? 0 : 1; // `lightRay.t > d` can only hold for finite d
+        prepare_shared(job, slot, o2, ld, so.origin, so.center, so.radius, so.reach_max, so.sign);
+        if (keys) {
+            key = rtg::oct_cell(-ld.x, -ld.y, -ld.z, so.key_bits);
+            keys[slot] = key;
+        }
+    }
+    if (keys && hist) {
+        const KeyGroup g = group_by_key(key, valid, (int)(threadIdx.x & 63));
+        if (valid && g.leader == (int)(threadIdx.x & 63)) atomicAdd(&hist[key], g.size);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -397,7 +432,8 @@ __device__ __forceinline__ void color_begin_slot(const RaySoA &r, int i, int slo
 //           the thread that files a ray under its slot prepares the slot too (intersect_setup_slot)
 //   MODE 1: ray indices with a finite origin                               -- before shading;
 //           the others are reference-grey (see color_finish_kernel) and get their pixel here;
-//           the thread that files a ray prepares its slot (color_begin_slot)
+//           the thread that files a ray prepares its slot (color_begin_slot) and the slot's shadow ray
+//           to the first light (shadow_setup_slot)
 //   MODE 2: slots of in_list (or 0..n-1 when in_list is null) whose shadow ray is not yet
 //           occluded (occ[slot] == 0)                                      -- between shadow chunks
 // ---------------------------------------------------------------------------
@@ -411,6 +447,8 @@ struct CompactWork { // what MODE 0 / MODE 1 do for each entry they file (unused
     unsigned int *keys, *hist;
     Scratch scratch;
     int *zero_this; // a counter zeroed for a later kernel of the stage call (see intersect_setup_kernel)
+    // MODE 1: the first light's shadow_setup_slot is done here too (job, so, keys and hist are its arguments)
+    float light0[3];
 };
 
 template <int MODE>
@@ -486,7 +524,15 @@ __global__ __launch_bounds__(BLOCK) void compact_kernel(RaySoA r, const int *__r
         if (has) out[slot] = value[it];
         if (MODE == 0)
             intersect_setup_slot(r, has, value[it], slot, work.job, work.best, work.shared, work.so, work.keys, work.hist);
-        if (MODE == 1 && has) color_begin_slot(r, value[it], slot, work.scratch);
+        if (MODE == 1) {
+            v3 o = rtx::V(0.0f, 0.0f, 0.0f);
+            if (has) {
+                color_begin_slot(slot, work.scratch);
+                o = rtx::V(r.ox[value[it]], r.oy[value[it]], r.oz[value[it]]);
+            }
+            shadow_setup_slot(has, slot, o, work.scratch, work.job, work.light0[0], work.light0[1], work.light0[2], work.so,
+                              work.keys, work.hist);
+        }
     }
     __syncthreads(); // s_cnt and s_base are reused by the next chunk
     }
@@ -2593,54 +2639,31 @@ __global__ __launch_bounds__(BLOCK) void shadow_setup_kernel(const int *__restri
         add_counter(counters, C_SH_RAYS, (unsigned long long)n);
         if (n_out) *n_out = n; // for the kernel log
     }
-    RT_FOR_EACH_SLOT(slot, n) {
-    const v3 lpos = rtx::V(lx, ly, lz);
-    v3 o = rtx::V(s.sox[slot], s.soy[slot], s.soz[slot]);
-    const v3 ld = rtx::normalize(rtx::sub(lpos, o));
-    const v3 o2 = rtx::add(o, rtx::muls(ld, 0.0000001f)); // shadow-ray origin
-    o = rtx::sub(o, rtx::muls(ld, 0.0000001f));           // r.origin = r.origin - lightDir * 1e-7
-    s.sox[slot] = o.x; s.soy[slot] = o.y; s.soz[slot] = o.z;
-    const float dist = rtx::distance3(lpos, o);
-    job.ox[slot] = o2.x; job.oy[slot] = o2.y; job.oz[slot] = o2.z;
-    job.dx[slot] = ld.x; job.dy[slot] = ld.y; job.dz[slot] = ld.z;
-    job.tmax[slot] = dist;
-    s.occ[slot] = (dist < INFINITY) ? 0 : 1; // `lightRay.t > d` can only hold for finite d
-    prepare_shared(job, slot, o2, ld, so.origin, so.center, so.radius, so.reach_max, so.sign);
-    // grouped by the cell of the direction in which the light sees them (rt_grid.h); the key is counted
-    // into hist[] here (bin_count_kernel's work; the lanes still in the loop do it together)
-    if (keys) {
-        const unsigned int key = rtg::oct_cell(-ld.x, -ld.y, -ld.z, so.key_bits);
-        keys[slot] = key;
-        if (hist) {
-            const KeyGroup g = group_by_key(key, true, (int)(threadIdx.x & 63));
-            if (g.leader == (int)(threadIdx.x & 63)) atomicAdd(&hist[key], g.size);
-        }
-    }
+    // (whole wavefronts stay in the loop: the lanes group their keys together)
+    for (int base = blockIdx.x * BLOCK; base < n; base += (int)gridDim.x * BLOCK) {
+        const int slot = base + (int)threadIdx.x;
+        const bool valid = slot < n;
+        v3 o = rtx::V(0.0f, 0.0f, 0.0f);
+        if (valid) o = rtx::V(s.sox[slot], s.soy[slot], s.soz[slot]);
+        shadow_setup_slot(valid, slot, o, s, job, lx, ly, lz, so, keys, hist);
     }
 }
 
-// spheres of the shadow trace, then raycol_cs.glsl:50-79 for the rays that reach the light
-__global__ __launch_bounds__(BLOCK) void shadow_finish_kernel(RaySoA r, const int *__restrict__ list0,
-                                                              const int *__restrict__ alist,
-                                                              const int *__restrict__ acount, int n_fixed, Scratch s,
-                                                              Job job, rt_light light, Camera cam)
+// spheres of the shadow trace, then raycol_cs.glsl:50-79 for a ray that reaches the light: false when
+// a sphere occludes it, else `add` = what the light contributes to the ray's `light` accumulator
+// (the caller has seen to it that no triangle occludes: occ[slot] == 0)
+__device__ __forceinline__ bool shadow_finish_slot(const RaySoA &r, int i, int slot, const Scratch &s, const Job &job,
+                                                   const rt_light &light, const Camera &cam, v3 &add)
 {
-    const int n = acount ? *acount : n_fixed;
-    RT_FOR_EACH_SLOT(a, n) {
-    const int slot = alist ? alist[a] : a;
-    if (s.occ[slot] != 0) continue;
     const v3 o2 = rtx::V(job.ox[slot], job.oy[slot], job.oz[slot]);
     const v3 ld = rtx::V(job.dx[slot], job.dy[slot], job.dz[slot]);
     const float dist = job.tmax[slot];
-    bool by_sphere = false;
 #pragma unroll
     for (int sp = 0; sp < 2; sp++) {
         float ts;
         if (rtx::ray_sphere(o2, ld, rtx::sphere_center(sp), rtx::sphere_radius(sp), ts))
-            if (ts > 0.0f && ts <= dist) by_sphere = true; // occluded by a sphere
+            if (ts > 0.0f && ts <= dist) return false; // occluded by a sphere
     }
-    if (by_sphere) continue;
-    const int i = list0[slot];
     const v3 o = rtx::V(s.sox[slot], s.soy[slot], s.soz[slot]);
     const v3 nn = rtx::V(r.nx[i], r.ny[i], r.nz[i]);
     const v3 lcol = rtx::V(light.color[0], light.color[1], light.color[2]);
@@ -2655,20 +2678,44 @@ __global__ __launch_bounds__(BLOCK) void shadow_finish_kernel(RaySoA r, const in
         kk = rtx::pow30(rtx::max0(rtx::dot(v, rr)));
     }
     const float att = 1.0f / (0.5f * dist);
-    const v3 add = rtx::muls(rtx::muls(lcol, diffuse + kk), att);
+    add = rtx::muls(rtx::muls(lcol, diffuse + kk), att);
+    return true;
+}
+
+// (every light but the last: the last light's share of this work is done by color_finish_kernel)
+__global__ __launch_bounds__(BLOCK) void shadow_finish_kernel(RaySoA r, const int *__restrict__ list0,
+                                                              const int *__restrict__ alist,
+                                                              const int *__restrict__ acount, int n_fixed, Scratch s,
+                                                              Job job, rt_light light, Camera cam)
+{
+    const int n = acount ? *acount : n_fixed;
+    RT_FOR_EACH_SLOT(a, n) {
+    const int slot = alist ? alist[a] : a;
+    if (s.occ[slot] != 0) continue;
+    v3 add;
+    if (!shadow_finish_slot(r, list0[slot], slot, s, job, light, cam, add)) continue;
     s.lr[slot] = s.lr[slot] + add.x; s.lg[slot] = s.lg[slot] + add.y; s.lb[slot] = s.lb[slot] + add.z;
     s.lit[slot] = 1;
     }
 }
 
 // texture, final colour, kill rule, pixel  (raycol_cs.glsl:82-127)
+// (and before that, for the LAST light, what shadow_finish_kernel does for the others: a slot's thread
+// adds that light's contribution itself -- one launch and one round trip through memory fewer)
 __global__ __launch_bounds__(BLOCK) void color_finish_kernel(RaySoA r, const int *__restrict__ list0,
                                                              const int *__restrict__ count, Scratch s,
                                                              const rt_vertex *__restrict__ verts, int num_vertices,
                                                              const uint32_t *__restrict__ tex, int tex_w, int tex_h,
-                                                             uint32_t *__restrict__ fb, int *zero_this, int *n_host)
+                                                             uint32_t *__restrict__ fb, int *zero_this, int *n_host,
+                                                             Job job, rt_light last_light, Camera cam,
+                                                             unsigned long long *counters, int *n_out0)
 {
     const int n = *count;
+    // the first light's shadow rays were prepared by the compaction, which could not count them
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        add_counter(counters, C_SH_RAYS, (unsigned long long)n);
+        if (n_out0) *n_out0 = n; // for the kernel log
+    }
     // feedback for the host's choices in later calls (pinned host memory; nobody waits for it)
     if (n_host && blockIdx.x == 0 && threadIdx.x == 0) *n_host = n;
     // the list counter of the OTHER stage, which no kernel of this stage call reads: zero for its next use
@@ -2676,7 +2723,16 @@ __global__ __launch_bounds__(BLOCK) void color_finish_kernel(RaySoA r, const int
     RT_FOR_EACH_SLOT(slot, n) {
     const int i = list0[slot];
     v3 fin = rtx::V(0.1f, 0.1f, 0.1f);
-    if (s.lit[slot]) {
+    float lr = s.lr[slot], lg = s.lg[slot], lb = s.lb[slot];
+    bool lit = s.lit[slot] != 0;
+    if (s.occ[slot] == 0) { // the last light's shadow ray met no triangle
+        v3 add;
+        if (shadow_finish_slot(r, i, slot, s, job, last_light, cam, add)) {
+            lr = lr + add.x; lg = lg + add.y; lb = lb + add.z;
+            lit = true;
+        }
+    }
+    if (lit) {
         const int id = r.id[i];
         v3 pa = rtx::V(0.0f, 0.0f, 0.0f), pb = pa, pc = pa;
         float ta0 = 0.0f, ta1 = 0.0f, tb0 = 0.0f, tb1 = 0.0f, tc0 = 0.0f, tc1 = 0.0f;
@@ -2702,7 +2758,7 @@ __global__ __launch_bounds__(BLOCK) void color_finish_kernel(RaySoA r, const int
             texc = rtx::V((float)(tx & 255u) / 255.0f, (float)((tx >> 8) & 255u) / 255.0f,
                           (float)((tx >> 16) & 255u) / 255.0f);
         }
-        fin = rtx::add(texc, rtx::muls(rtx::V(s.lr[slot], s.lg[slot], s.lb[slot]), 0.3f));
+        fin = rtx::add(texc, rtx::muls(rtx::V(lr, lg, lb), 0.3f));
         if (id + 3 * 5 - 2 < num_vertices / 3) {
             r.id[i] = -2;
             r.ox[i] = o.x; r.oy[i] = o.y; r.oz[i] = o.z;
