@@ -507,15 +507,21 @@ def main():
             g.counters(); g.kernel_log()
             out["stage_ms_per_step_one_frame_at_a_time"] = {"raygen": stage_ms[0] / solo_steps, "intersect": stage_ms[1] / solo_steps,
                                                             "color": stage_ms[2] / solo_steps}
-            steps = solo_steps
-        if on_gpu and stage_ms[0] > 0:
-            # raygen: 14 planes of one float written per ray, nothing read
-            frames = max(1, len(getattr(job, "mine", [0])))  # raygen launches per step on this rank
-            gbs = RAY_PLANE_BYTES * g.num_rays * steps * frames / (stage_ms[0] * 1e-3) / 1e9
-            pmc = committed_counters(args.workload if world == 1 else None)[0].get("rtk::raygen_kernel", {})
+        if on_gpu and world == 1:
+            # raygen: 14 planes of one float written per ray, nothing read.  Ten launches of rt_raygen alone, each
+            # between an event pair of its own (inside rt_render the stage's closing event also opens the next stage)
+            sync_all()
+            g.stage_ms()
+            launches = 10
+            for _ in range(launches):
+                g.raygen()
+            g.sync()
+            ms = g.stage_ms()[0] / launches
+            gbs = RAY_PLANE_BYTES * g.num_rays / (ms * 1e-3) / 1e9
+            pmc = committed_counters(args.workload)[0].get("rtk::raygen_kernel", {})
             out["roofline_raygen"] = {"bound": "hbm", "kernel": "rtk::raygen_kernel", "achieved": gbs, "peak": PEAK_HBM_GBS,
                                       "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": pmc.get("hbm_bytes_per_launch"),
-                                      "avg_launch_ms": stage_ms[0] / (steps * frames),
+                                      "avg_launch_ms": ms, "launches": launches,
                                       "bytes_per_launch": RAY_PLANE_BYTES * g.num_rays}
         if on_gpu and world == 1 and args.trace_mode == 2 and not args.no_kernel_rooflines:
             job = solo or job

@@ -25,11 +25,26 @@ for r in stats[:24]:
                  f"{float(r['TotalDurationNs'])/1e6:10.2f} {float(r['Percentage']):6.2f}")
 dur = {short(r["Name"]): (float(r["AverageNs"]) * 1e-9, int(r["Calls"])) for r in stats}
 
+# raygen also runs on the 1/32 tile share that the all-pairs measurement renders: only its whole-frame launches
+# (the largest grid) are summarised
+FULL_FRAME_ONLY = ("rtk::raygen_kernel",)
+trace = list(csv.DictReader(open(f"{base}/trace/t_kernel_trace.csv")))
+for name in FULL_FRAME_ONLY:
+    rows = [r for r in trace if short(r["Kernel_Name"]) == name]
+    if rows:
+        gmax = max(int(r["Grid_Size_X"]) for r in rows)
+        full = [r for r in rows if int(r["Grid_Size_X"]) == gmax]
+        dur[name] = (sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in full) / len(full) * 1e-9, len(full))
+
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 calls = collections.defaultdict(set)
 for f in ("pmc_sq/sq", "pmc_fetch/f", "pmc_write/w", "pmc_misc/m"):
-    for r in csv.DictReader(open(f"{base}/{f}_counter_collection.csv")):
+    rows = list(csv.DictReader(open(f"{base}/{f}_counter_collection.csv")))
+    gmax = {name: max([int(r["Grid_Size"]) for r in rows if short(r["Kernel_Name"]) == name] or [0]) for name in FULL_FRAME_ONLY}
+    for r in rows:
         k = short(r["Kernel_Name"])
+        if k in gmax and int(r["Grid_Size"]) != gmax[k]:
+            continue
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         calls[(k, f)].add(r["Dispatch_Id"])
 lines.append("")
