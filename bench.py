@@ -315,6 +315,9 @@ def main():
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal on a box with fewer GPUs than ranks: rank r renders on GPU r %% (GPUs present); "
                          "use with --backend gloo (RCCL wants a GPU per rank)")
+    ap.add_argument("--rehearse-collectives", action="store_true",
+                    help="one rank: open a process group of one rank all the same and run every collective of the "
+                         "multi-rank path (the gather of each frame, barrier, all-reduce) through it")
     ap.add_argument("--renderer", choices=("hip", "oracle"), default="hip",
                     help="oracle: the CPU restatement stands in for the GPU (tests of this program's launcher only)")
     args = ap.parse_args()
@@ -340,8 +343,15 @@ def main():
         torch.cuda.set_stream(torch.cuda.Stream(dev))
     # where the pixels are gathered from: device tensors over RCCL; host tensors with any other backend
     shard_dev = dev if (on_gpu and args.backend == "nccl") else torch.device("cpu")
-    if world > 1:
+    collectives = world > 1 or args.rehearse_collectives
+    if collectives:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            import socket
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            sk.close()
         if on_gpu and args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -377,10 +387,12 @@ def main():
 
     def make_job(renderers):
         if wl["kind"] == "tiles" and (world == 1 or mode == "tiles"):
-            return sharding.TileShardedFrame(renderers, wl["width"], wl["height"], shard_dev, bind_device_framebuffer=on_gpu)
+            return sharding.TileShardedFrame(renderers, wl["width"], wl["height"], shard_dev, bind_device_framebuffer=on_gpu,
+                                             gather_always=collectives)
         # whole frames: one frame of a single-frame workload per rank per step, or the workload's views dealt out
         cams = wl["cams"] * world if wl["kind"] == "tiles" else wl["cams"]
-        return sharding.FrameBatch(renderers, wl["width"], wl["height"], cams, shard_dev, bind_device_framebuffer=on_gpu)
+        return sharding.FrameBatch(renderers, wl["width"], wl["height"], cams, shard_dev, bind_device_framebuffer=on_gpu,
+                                   gather_always=collectives)
 
     job = make_job(gs)
     if isinstance(job, sharding.TileShardedFrame):
@@ -400,7 +412,7 @@ def main():
             for q in gs:
                 q.sync()
             torch.cuda.synchronize(dev)
-        if world > 1:
+        if collectives:
             dist.barrier()
             if on_gpu:
                 torch.cuda.synchronize(dev)
@@ -444,7 +456,7 @@ def main():
                         cnt["closest_candidates"], cnt["shadow_candidates"], cnt["closest_slow_steps"],
                         cnt["shadow_slow_steps"]], dtype=torch.float64, device=shard_dev)
     tmax = torch.tensor([dt], dtype=torch.float64, device=shard_dev)
-    if world > 1:
+    if collectives:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     tot = tot.cpu().numpy()
@@ -473,7 +485,7 @@ def main():
                        "height": wl["height"], "views": views, "triangles": int(wl["mesh"].shape[0] // 3),
                        "passes": wl["passes"], "lights": wl["lights"], "sharding": shard_desc,
                        "trace_mode": ("filtered", "exact", "clustered")[args.trace_mode], "options": args.opt,
-                       "frames_in_flight": in_flight,
+                       "frames_in_flight": in_flight, "rehearse_collectives": bool(args.rehearse_collectives),
                        "rays_per_step": rays / steps,
                        "closest_hit_rays_per_step": tot[0] / steps, "shadow_rays_per_step": tot[1] / steps,
                        # the reference traces a shadow ray per light for every pixel in every pass, dead
@@ -539,7 +551,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl)
         print(json.dumps(out))
-    if world > 1:
+    if collectives:
         dist.barrier()
         dist.destroy_process_group()
     if on_gpu:

@@ -83,12 +83,15 @@ class TileShardedFrame:
     """One frame cut into interleaved row tiles over the ranks of the default process group.
     `renderer`: one renderer, or a list of them for that many frames in flight."""
 
-    def __init__(self, renderer, width, height, device, tile_rows=None, bind_device_framebuffer=True):
+    def __init__(self, renderer, width, height, device, tile_rows=None, bind_device_framebuffer=True,
+                 gather_always=False):
         self.rs = _as_list(renderer)
         self.r = self.rs[0]
         self.width, self.height = int(width), int(height)
         self.device = torch.device(device)
         self.rank, self.world = _world()
+        # (gather_always: a process group of ONE rank gathers too -- a rehearsal of the collective path)
+        self.gather = self.world > 1 or (gather_always and dist.is_available() and dist.is_initialized())
         self.tile_rows = tile_rows or choose_tile_rows(self.height, self.world)
         for r in self.rs:
             r.set_row_tiles(self.tile_rows, self.rank, self.world)
@@ -128,7 +131,7 @@ class TileShardedFrame:
             if not self.bound:
                 px = torch.from_numpy(np.ascontiguousarray(r.read_pixels()))
                 local[: px.shape[0]].copy_(px)
-            if self.world == 1:
+            if not self.gather:
                 return local[: self.height]  # one rank owns every tile, rows already in order
             dist.gather(local, self.gathered[i] if self.rank == 0 else None, dst=0)
             if self.rank != 0:
@@ -144,12 +147,13 @@ class TileShardedFrame:
 class FrameBatch:
     """A batch of camera views, view k rendered by rank k % world; frames gathered to rank 0."""
 
-    def __init__(self, renderer, width, height, cameras, device, bind_device_framebuffer=True):
+    def __init__(self, renderer, width, height, cameras, device, bind_device_framebuffer=True, gather_always=False):
         self.rs = _as_list(renderer)
         self.r = self.rs[0]
         self.width, self.height = int(width), int(height)
         self.device = torch.device(device)
         self.rank, self.world = _world()
+        self.gather = self.world > 1 or (gather_always and dist.is_available() and dist.is_initialized())
         self.cameras = list(cameras)
         self.mine = list(range(self.rank, len(self.cameras), self.world))
         self.max_views = (len(self.cameras) + self.world - 1) // self.world
@@ -177,7 +181,7 @@ class FrameBatch:
             for r in self.rs:
                 r.bind_framebuffer(0)
             self.streams.wait()
-        if self.world == 1:
+        if not self.gather:
             return self.local[: len(self.cameras)]
         dist.gather(self.local, self.gathered if self.rank == 0 else None, dst=0)
         if self.rank != 0:

@@ -490,3 +490,26 @@ def test_frames_in_flight_tiles_on_three_contexts(rt, oracle_mod):
     finally:
         for g in gs:
             g.close()
+
+
+# -- the benchmark program's collective path, rehearsed on one rank ----------------------------------
+@pytest.mark.parametrize("workload", ["soup64k_4k_p6", "soup256k_64views_1080p"])
+def test_bench_collectives_rehearsed_on_one_rank(workload):
+    """bench.py with a process group of ONE rank over RCCL: every frame (or batch of views) goes
+    through the gather, on the streams of three contexts in flight, and the timing through barrier
+    and all-reduce, exactly as with N ranks.  The gathered pixels equal those of a plain run with
+    one frame at a time (the checksum bench.py prints)."""
+    import json
+
+    def run(*flags):
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", "3", "--warmup", "1",
+               "--no-cpu-baseline", "--no-kernel-rooflines", *flags]
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=110)
+        assert p.returncode == 0, p.stderr[-3000:]
+        return json.loads(p.stdout.strip().splitlines()[-1])
+
+    plain = run("--frames-in-flight", "1")
+    rehearsed = run("--rehearse-collectives")
+    assert rehearsed["config"]["rehearse_collectives"] and rehearsed["config"]["frames_in_flight"] == 3
+    assert plain["config"]["frame_crc32"] == rehearsed["config"]["frame_crc32"]
+    assert rehearsed["config"]["rays_per_step"] == plain["config"]["rays_per_step"]
