@@ -2446,7 +2446,12 @@ __global__ __launch_bounds__(BLOCK) void traverse_voxel_long_kernel(TraversePara
     __shared__ int s_first_all[BLOCK / 64][65];           // position of each cell's list in the concatenation
     __shared__ unsigned int s_start_all[BLOCK / 64][64];  // where each list starts in vox_entries
     __shared__ float s_enter_all[BLOCK / 64][64];         // parameter at which each cell is entered
+    __shared__ int s_rcell_all[BLOCK / 64][65];           // the walk's next 65 states: cell ...
+    __shared__ float s_renter_all[BLOCK / 64][65];        // ... and the parameter at which it is entered
+    __shared__ int s_next_all[BLOCK / 64][4];             // cell indices of the last of them
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int *s_rcell = s_rcell_all[wave], *s_next = s_next_all[wave];
+    float *s_renter = s_renter_all[wave];
     int *s_first = s_first_all[wave];
     unsigned int *s_start = s_start_all[wave];
     float *s_enter = s_enter_all[wave];
@@ -2467,18 +2472,56 @@ __global__ __launch_bounds__(BLOCK) void traverse_voxel_long_kernel(TraversePara
         bool alive = rtv::walk_start(G, ox, oy, oz, dx, dy, dz, w, t_from);
         bool walk_over = false;
         while (alive) {
-            // the next 64 cells of the walk: lane k keeps the k-th
-            int my_cell = -1;
-            float my_enter = INFINITY;
-            for (int k = 0; k < 64; k++) {
-                if (lane == k) {
-                    my_cell = rtv::cell_index(G, w);
-                    my_enter = w.t_enter;
-                }
-                if (!rtv::walk_step(G, ox, oy, oz, w)) {
-                    walk_over = true;
-                    break;
-                }
+            // the next 64 cells of the walk: lane k keeps the k-th.  Found by rank, not by stepping (rt_voxel.h,
+            // "The cells of a walk by rank"): lane L ranks event L of each axis among all the events; the event
+            // of rank r puts the walk into its state r + 1, which lane r + 1 takes from the table.
+            rtv::AxisSeq sx, sy, sz;
+            rtv::walk_sequences(G, ox, oy, oz, dx, dy, dz, w, sx, sy, sz);
+            if (lane == 0) {
+                s_rcell[0] = rtv::cell_index(G, w);
+                s_renter[0] = w.t_enter;
+            }
+            float te;
+            int cb, cc;
+            const int rx = rtv::event_rank(G, sx, lane, sy, false, sz, false, te, cb, cc);
+            if (rx < 64) {
+                const int ix = rtv::seq_index(sx, lane + 1), iy = rtv::seq_index(sy, cb), iz = rtv::seq_index(sz, cc);
+                s_rcell[rx + 1] = (iz * G.ny + iy) * G.nx + ix;
+                s_renter[rx + 1] = te;
+                if (rx == 63) { s_next[0] = ix; s_next[1] = iy; s_next[2] = iz; }
+            }
+            const int ry = rtv::event_rank(G, sy, lane, sx, true, sz, false, te, cb, cc);
+            if (ry < 64) {
+                const int ix = rtv::seq_index(sx, cb), iy = rtv::seq_index(sy, lane + 1), iz = rtv::seq_index(sz, cc);
+                s_rcell[ry + 1] = (iz * G.ny + iy) * G.nx + ix;
+                s_renter[ry + 1] = te;
+                if (ry == 63) { s_next[0] = ix; s_next[1] = iy; s_next[2] = iz; }
+            }
+            const int rz = rtv::event_rank(G, sz, lane, sx, true, sy, true, te, cb, cc);
+            if (rz < 64) {
+                const int ix = rtv::seq_index(sx, cb), iy = rtv::seq_index(sy, cc), iz = rtv::seq_index(sz, lane + 1);
+                s_rcell[rz + 1] = (iz * G.ny + iy) * G.nx + ix;
+                s_renter[rz + 1] = te;
+                if (rz == 63) { s_next[0] = ix; s_next[1] = iy; s_next[2] = iz; }
+            }
+            // the step that leaves the grid: the first of the three axes' exit events (each held by one lane)
+            const int ex = rtv::seq_exit_event(sx), ey = rtv::seq_exit_event(sy), ez = rtv::seq_exit_event(sz);
+            int r_exit = 1 << 20;
+            if (ex < 64) r_exit = min(r_exit, __shfl(rx, ex, 64));
+            if (ey < 64) r_exit = min(r_exit, __shfl(ry, ey, 64));
+            if (ez < 64) r_exit = min(r_exit, __shfl(rz, ez, 64));
+            if (r_exit < 64) walk_over = true;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // the other lanes read these
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // (states beyond the step that leaves the grid do not exist)
+            const int my_cell = lane <= r_exit ? s_rcell[lane] : -1;
+            const float my_enter = lane <= r_exit ? s_renter[lane] : INFINITY;
+            if (!walk_over) { // the state after 64 steps: where the next round starts
+                w.ix = s_next[0]; w.iy = s_next[1]; w.iz = s_next[2];
+                w.t_enter = s_renter[64];
+                sx.i0 = w.ix; sy.i0 = w.iy; sz.i0 = w.iz;
+                w.tx = rtv::seq_t(G, sx, 0); w.ty = rtv::seq_t(G, sy, 0); w.tz = rtv::seq_t(G, sz, 0);
             }
             unsigned int start = 0;
             int cnt = 0;

@@ -163,6 +163,80 @@ RT_HD bool walk_done_at(const Grid &G, float inv_dn, float t_enter, float tbest)
 RT_HD bool walk_done(const Grid &G, const Walk &w, float tbest) { return walk_done_at(G, w.inv_dn, w.t_enter, tbest); }
 
 // ---------------------------------------------------------------------------------------------
+// The cells of a walk by rank.  walk_step() finds the cells one after the other; a wavefront that
+// wants the next 64 cells of ONE walk at once (traverse_voxel_long_kernel) would have every lane repeat
+// those 64 steps.  But the walk is a merge of three sorted sequences: along each axis the line leaves
+// the cells i0, i0 +- 1, i0 +- 2, ... at parameters that depend on the cell's index alone,
+//     E(m) = axis_exit(i0 +- m)          ("event" m of the axis: the step from i0 +- m to i0 +- (m + 1)),
+// nondecreasing in m (every operation of axis_exit is monotone), and walk_step() always takes the
+// smallest of the three pending parameters, x before y before z among equal ones.  Step number r of
+// the walk is therefore the event of rank r in the order (parameter, axis, m), and the rank of event
+// L of an axis is L + (events of the other two axes that come before it), two binary searches.  Lane
+// L of a wavefront ranks event L of each axis; the event of rank r yields the walk's state after
+// r + 1 steps.  tests/native/filter_model.cpp checks, on the host, that this reproduces walk_step()'s
+// sequence state for state.
+// ---------------------------------------------------------------------------------------------
+RT_HD float axis_exit(const Grid &G, float gmin, int i, float o, float inv)
+{
+    return (fmaf((float)(inv > 0.0f ? i + 1 : i), G.cs, gmin) - o) * inv; // as exit_param() and walk_step() form it
+}
+
+struct AxisSeq {  // the events of one axis, counted from the walk's current cell
+    float gmin, o, inv;
+    int i0, n;    // current index, cells along the axis
+    bool flat;    // the axis is not stepped (walk_start's criterion): its events never come
+};
+
+RT_HD int seq_index(const AxisSeq &s, int m) { return s.inv > 0.0f ? s.i0 + m : s.i0 - m; }
+RT_HD float seq_t(const Grid &G, const AxisSeq &s, int m)
+{
+    return s.flat ? INFINITY : axis_exit(G, s.gmin, seq_index(s, m), s.o, s.inv);
+}
+
+// how many of the events 0..63 of s come before an event at parameter t of another axis; ties_first: an
+// event of s at exactly t comes first (s's axis has priority)
+RT_HD int seq_count_before(const Grid &G, const AxisSeq &s, float t, bool ties_first)
+{
+    int c = 0;
+#define RT_SEQ_BEFORE(m) (seq_t(G, s, (m)) < t || (ties_first && seq_t(G, s, (m)) == t))
+    for (int sh = 32; sh > 0; sh >>= 1)
+        if (RT_SEQ_BEFORE(c + sh - 1)) c += sh;
+    if (c == 63 && RT_SEQ_BEFORE(63)) c = 64;
+#undef RT_SEQ_BEFORE
+    return c;
+}
+
+// Event L of axis a (b, c: the other two axes; b_first / c_first: their events win ties against a's).
+// Returns its rank; t: its parameter; cb, cc: the events of b and c before it.  After it the walk is in
+// cell (seq_index(a, L + 1), seq_index(b, cb), seq_index(c, cc)), entered at t.
+RT_HD int event_rank(const Grid &G, const AxisSeq &a, int L, const AxisSeq &b, bool b_first, const AxisSeq &c,
+                     bool c_first, float &t, int &cb, int &cc)
+{
+    t = seq_t(G, a, L);
+    cb = seq_count_before(G, b, t, b_first);
+    cc = seq_count_before(G, c, t, c_first);
+    return L + cb + cc;
+}
+
+// the three sequences of a walk in its current state (d: the ray's direction, as given to walk_start)
+RT_HD void walk_sequences(const Grid &G, float ox, float oy, float oz, float dx, float dy, float dz, const Walk &w,
+                          AxisSeq &sx, AxisSeq &sy, AxisSeq &sz)
+{
+    const float dn = sqrtf(dx * dx + dy * dy + dz * dz);
+    const float lim = dn * G.flat;
+    sx = AxisSeq{G.gminx, ox, w.invx, w.ix, G.nx, !(fabsf(dx) > lim)};
+    sy = AxisSeq{G.gminy, oy, w.invy, w.iy, G.ny, !(fabsf(dy) > lim)};
+    sz = AxisSeq{G.gminz, oz, w.invz, w.iz, G.nz, !(fabsf(dz) > lim)};
+}
+
+// the event of an axis that leaves the grid: 64 or more when it is not among the next 64
+RT_HD int seq_exit_event(const AxisSeq &s)
+{
+    if (s.flat) return 1 << 20;
+    return s.inv > 0.0f ? s.n - 1 - s.i0 : s.i0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Host-side build.
 // ---------------------------------------------------------------------------------------------
 struct VoxelSet {

@@ -489,3 +489,96 @@ extern "C" void fm_check_band_cells(int n_tris, const float *verts, int n_rays, 
     }
     stats[0] = pairs; stats[1] = listed_n; stats[2] = pass_n; stats[3] = bad;
 }
+
+// ---------------------------------------------------------------------------------------------
+// The cells of a walk by rank (rt_voxel.h: event_rank and friends, what traverse_voxel_long_kernel's 64
+// lanes compute together) against the cells walk_step() finds one after the other, on a grid given by
+// its corner, cell size and cell counts, round after round of 64 steps until the walk leaves the grid:
+// every state's cell and entry parameter, the step that leaves the grid, and the state a round hands to
+// the next (indices and the three exit parameters), bit for bit.
+// stats: [0] walks [1] states compared [2] mismatches [3] rounds [4] walks that never entered the grid
+// ---------------------------------------------------------------------------------------------
+extern "C" void fm_check_walk_ranks(const float *gmin, float cs, const int *n, float back, float flat, int n_rays,
+                                    const float *org, const float *dir, long long *stats)
+{
+    rtv::Grid G{};
+    G.gminx = gmin[0]; G.gminy = gmin[1]; G.gminz = gmin[2];
+    G.cs = cs; G.inv_cs = 1.0f / cs;
+    G.nx = n[0]; G.ny = n[1]; G.nz = n[2];
+    G.gmaxx = rtv::plane_at(G, G.gminx, G.nx); G.gmaxy = rtv::plane_at(G, G.gminy, G.ny); G.gmaxz = rtv::plane_at(G, G.gminz, G.nz);
+    G.back = back; G.slack = 0.0f; G.flat = flat;
+    long long walks = 0, states = 0, bad = 0, rounds = 0, outside = 0;
+    auto bits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
+#pragma omp parallel for schedule(dynamic, 64) reduction(+ : walks, states, bad, rounds, outside)
+    for (int i = 0; i < n_rays; i++) {
+        const float *o = org + 3 * i, *d = dir + 3 * i;
+        rtv::Walk w{};
+        if (!rtv::walk_start(G, o[0], o[1], o[2], d[0], d[1], d[2], w)) { outside++; continue; }
+        walks++;
+        for (bool over = false; !over;) {
+            rounds++;
+            // one after the other: states 0..64 from here, and the step that fails
+            rtv::Walk seq[65];
+            int fail_step = 1 << 20;
+            seq[0] = w;
+            for (int k = 0; k < 64; k++) {
+                seq[k + 1] = seq[k];
+                if (!rtv::walk_step(G, o[0], o[1], o[2], seq[k + 1])) { fail_step = k; break; }
+            }
+            // by rank
+            rtv::AxisSeq sx, sy, sz;
+            rtv::walk_sequences(G, o[0], o[1], o[2], d[0], d[1], d[2], w, sx, sy, sz);
+            int cell[65], nxt[3] = {0, 0, 0}, filled[65] = {0};
+            float enter[65];
+            cell[0] = rtv::cell_index(G, w); enter[0] = w.t_enter; filled[0] = 1;
+            int rank[3][64];
+            for (int L = 0; L < 64; L++) {
+                float te; int cb, cc;
+                int r = rtv::event_rank(G, sx, L, sy, false, sz, false, te, cb, cc);
+                rank[0][L] = r;
+                if (r < 64) {
+                    const int ix = rtv::seq_index(sx, L + 1), iy = rtv::seq_index(sy, cb), iz = rtv::seq_index(sz, cc);
+                    cell[r + 1] = (iz * G.ny + iy) * G.nx + ix; enter[r + 1] = te; filled[r + 1]++;
+                    if (r == 63) { nxt[0] = ix; nxt[1] = iy; nxt[2] = iz; }
+                }
+                r = rtv::event_rank(G, sy, L, sx, true, sz, false, te, cb, cc);
+                rank[1][L] = r;
+                if (r < 64) {
+                    const int ix = rtv::seq_index(sx, cb), iy = rtv::seq_index(sy, L + 1), iz = rtv::seq_index(sz, cc);
+                    cell[r + 1] = (iz * G.ny + iy) * G.nx + ix; enter[r + 1] = te; filled[r + 1]++;
+                    if (r == 63) { nxt[0] = ix; nxt[1] = iy; nxt[2] = iz; }
+                }
+                r = rtv::event_rank(G, sz, L, sx, true, sy, true, te, cb, cc);
+                rank[2][L] = r;
+                if (r < 64) {
+                    const int ix = rtv::seq_index(sx, cb), iy = rtv::seq_index(sy, cc), iz = rtv::seq_index(sz, L + 1);
+                    cell[r + 1] = (iz * G.ny + iy) * G.nx + ix; enter[r + 1] = te; filled[r + 1]++;
+                    if (r == 63) { nxt[0] = ix; nxt[1] = iy; nxt[2] = iz; }
+                }
+            }
+            const int ex = rtv::seq_exit_event(sx), ey = rtv::seq_exit_event(sy), ez = rtv::seq_exit_event(sz);
+            int r_exit = 1 << 20;
+            if (ex < 64) r_exit = std::min(r_exit, rank[0][ex]);
+            if (ey < 64) r_exit = std::min(r_exit, rank[1][ey]);
+            if (ez < 64) r_exit = std::min(r_exit, rank[2][ez]);
+            if (r_exit >= 64) r_exit = 1 << 20;
+            bad += r_exit != fail_step;
+            const int last = fail_step < 64 ? fail_step : 64; // states 0..last exist
+            for (int k = 0; k <= last; k++) {
+                states++;
+                bad += filled[k] != 1 || cell[k] != rtv::cell_index(G, seq[k]) || bits(enter[k]) != bits(seq[k].t_enter);
+            }
+            if (fail_step < 64) { over = true; continue; }
+            rtv::Walk nw = w;
+            nw.ix = nxt[0]; nw.iy = nxt[1]; nw.iz = nxt[2];
+            nw.t_enter = enter[64];
+            sx.i0 = nw.ix; sy.i0 = nw.iy; sz.i0 = nw.iz;
+            nw.tx = rtv::seq_t(G, sx, 0); nw.ty = rtv::seq_t(G, sy, 0); nw.tz = rtv::seq_t(G, sz, 0);
+            const rtv::Walk &ref = seq[64];
+            bad += nw.ix != ref.ix || nw.iy != ref.iy || nw.iz != ref.iz || bits(nw.tx) != bits(ref.tx) ||
+                   bits(nw.ty) != bits(ref.ty) || bits(nw.tz) != bits(ref.tz) || bits(nw.t_enter) != bits(ref.t_enter);
+            w = nw;
+        }
+    }
+    stats[0] = walks; stats[1] = states; stats[2] = bad; stats[3] = rounds; stats[4] = outside;
+}

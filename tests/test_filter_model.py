@@ -737,3 +737,69 @@ def test_band_cells_hold_every_member_a_ray_is_inside(fm, bits):
     assert st["passes"] > 1000, st
     if bits >= 8:
         assert st["listed"] < 0.5 * st["pairs"], st   # the slivers among the nasty triangles are in every band
+
+
+# -- the cells of a walk by rank (traverse_voxel_long_kernel) against the cells found step by step -----------
+def run_walk_ranks(fm, gmin, cs, n, back, flat, org, dirs):
+    org = np.ascontiguousarray(org, dtype=f32)
+    dirs = np.ascontiguousarray(dirs, dtype=f32)
+    gmin = np.ascontiguousarray(gmin, dtype=f32)
+    n = np.ascontiguousarray(n, dtype=np.int32)
+    st = np.zeros(8, dtype=np.int64)
+    fm.fm_check_walk_ranks.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_void_p,
+                                       C.c_void_p, C.c_void_p]
+    fm.fm_check_walk_ranks(gmin.ctypes.data, cs, n.ctypes.data, back, flat, org.shape[0], org.ctypes.data,
+                           dirs.ctypes.data, st.ctypes.data)
+    return dict(walks=int(st[0]), states=int(st[1]), bad=int(st[2]), rounds=int(st[3]), outside=int(st[4]))
+
+
+def walk_rays(rs, n, lo, hi):
+    """Origins inside and around the box [lo, hi], directions of every kind: random, nearly and exactly
+    axis-parallel, exactly diagonal (every step a tie between axes), through cell corners, tiny and huge."""
+    span = hi - lo
+    org = rs.uniform(lo - 0.3 * span, hi + 0.3 * span, (n, 3))
+    d = rs.normal(size=(n, 3))
+    kind = rs.randint(0, 8, n)
+    ax = rs.randint(0, 3, n)
+    for i in range(n):
+        k = kind[i]
+        if k == 1:      # exactly axis-parallel
+            d[i] = 0.0; d[i, ax[i]] = rs.choice([-1.0, 1.0])
+        elif k == 2:    # nearly axis-parallel: one or two components below / around the "flat" threshold
+            d[i, (ax[i] + 1) % 3] *= 10.0 ** rs.uniform(-9, -3)
+            d[i, (ax[i] + 2) % 3] *= 10.0 ** rs.uniform(-9, -3)
+        elif k == 3:    # exact diagonals: equal parameters on two or three axes at every step
+            d[i] = rs.choice([-1.0, 1.0], 3) * rs.choice([1.0, 1.0, 0.0], 3)
+            if not d[i].any():
+                d[i, 0] = 1.0
+        elif k == 4:    # scaled: |d| far from 1
+            d[i] *= 10.0 ** rs.uniform(-12, 12)
+        elif k == 5:    # through (or a hair beside) a corner of the cell grid, from a point on the grid
+            org[i] = lo + np.round((org[i] - lo) * 8) / 8
+            d[i] = np.round(d[i] * 2) / 2
+            if not d[i].any():
+                d[i, 1] = -1.0
+    return org.astype(f32), d.astype(f32)
+
+
+def test_walk_by_rank_equals_walk_by_steps(fm):
+    rs = np.random.RandomState(1234)
+    total = rounds = walks = 0
+    # grids of 64^3 cells of 1/32 (corners and diagonals exact in binary), of odd sizes, long and flat, offset far away
+    for gmin, cs, n in [((-1.0, -1.0, -1.0), 1.0 / 32, (64, 64, 64)),
+                        ((-1.07, -0.93, -1.21), 0.0371, (61, 57, 70)),
+                        ((-3.0, -0.2, -0.1), 0.05, (130, 9, 3)),
+                        ((999.0, -1001.0, 0.3), 0.0219, (128, 100, 77)),
+                        ((-0.5, -0.5, -0.5), 1.0, (1, 1, 1))]:
+        lo = np.array(gmin)
+        hi = lo + cs * np.array(n)
+        org, d = walk_rays(rs, 30000, lo, hi)
+        for back, flat in ((0.08, 1e-7), (0.0, 0.0)):
+            st = run_walk_ranks(fm, gmin, cs, n, back, flat, org, d)
+            assert st["bad"] == 0, (gmin, cs, n, st)
+            assert st["walks"] > 5000, st
+            total += st["states"]
+            rounds += st["rounds"]
+            walks += st["walks"]
+    assert total > 3_000_000
+    assert rounds > 1.2 * walks   # walks of several rounds of 64 steps among them
