@@ -148,6 +148,17 @@ def cpu_baseline(wl, seconds_hint=15.0):
                       f"{wl['passes']} passes, oracle with {threads} OpenMP threads, {dt:.1f} s"}
 
 
+def committed_frame(workload_name):
+    """VALU wave-instructions of one whole frame of the workload, from the same committed counter run."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic_per_launch.json")))
+        if rec.get("workload") != workload_name or not rec.get("frame"):
+            return None
+        return rec["frame"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def committed_counters(workload_name):
     """Per-launch hardware counters of the kernels from the committed PMC summary (separate rocprofv3
     runs of this program with --sweeps-in-turn: counters cannot be read from inside the benchmark)."""
@@ -558,6 +569,20 @@ def main():
                                "1024 SIMDs x 0.25 wave-instructions per clock (16 lanes per SIMD) x 2.4 GHz")
                 out["roofline"] = dom
                 out["roofline_kernels"] = per_kernel
+            fr = committed_frame(args.workload)
+            if fr and fr.get("valu_wave_insts"):
+                # the whole frame against the same roof: every kernel's instructions (one frame of the committed
+                # counter run) over the frame time of the timed region
+                ginst = float(fr["valu_wave_insts"]) / (dt / steps) / 1e9
+                if ginst <= PEAK_VALU_GINST:
+                    out["roofline_frame"] = {"bound": "valu", "achieved": ginst, "peak": PEAK_VALU_GINST,
+                                             "unit": "G VALU wave-instructions/s", "frac": ginst / PEAK_VALU_GINST,
+                                             "valu_wave_insts_per_frame": fr["valu_wave_insts"],
+                                             "kernels_per_frame": fr.get("dispatches"), "ms_per_frame": dt / steps * 1e3,
+                                             "frames_in_flight": in_flight,
+                                             "note": "all " + str(fr.get("dispatches")) + " kernels of a frame: executed VALU "
+                                                     "wave-instructions per frame (committed PMC summary) / the timed "
+                                                     "region's time per frame / the issue peak"}
             if wl["kind"] == "tiles":
                 out["roofline_exact_mode"] = exact_mode_roofline(g, job, wl)
         if world == 1 and not args.no_cpu_baseline:

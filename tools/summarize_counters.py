@@ -47,6 +47,20 @@ for f in ("pmc_sq/sq", "pmc_fetch/f", "pmc_write/w", "pmc_misc/m"):
             continue
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         calls[(k, f)].add(r["Dispatch_Id"])
+# one whole frame of the counter run: the dispatches from one whole-frame raygen up to the next
+frame = None
+sq_rows = list(csv.DictReader(open(f"{base}/pmc_sq/sq_counter_collection.csv")))
+gen = sorted({int(r["Dispatch_Id"]) for r in sq_rows if short(r["Kernel_Name"]) == "rtk::raygen_kernel"
+              and int(r["Grid_Size"]) == max(int(q["Grid_Size"]) for q in sq_rows if short(q["Kernel_Name"]) == "rtk::raygen_kernel")})
+if len(gen) >= 4:
+    lo, hi = gen[2], gen[3]
+    sel = [r for r in sq_rows if lo <= int(r["Dispatch_Id"]) < hi]
+    frame = {"valu_wave_insts": sum(float(r["Counter_Value"]) for r in sel if r["Counter_Name"] == "SQ_INSTS_VALU"),
+             "salu_wave_insts": sum(float(r["Counter_Value"]) for r in sel if r["Counter_Name"] == "SQ_INSTS_SALU"),
+             "dispatches": len({r["Dispatch_Id"] for r in sel})}
+    lines.append("")
+    lines.append(f"== one whole frame (dispatches {lo}..{hi - 1} of the SQ counter run): {frame['dispatches']} kernels, "
+                 f"SQ_INSTS_VALU {frame['valu_wave_insts']:.4g}, SQ_INSTS_SALU {frame['salu_wave_insts']:.4g} ==")
 lines.append("")
 lines.append("== hardware counters, per launch (each --pmc set collected in a run of its own) ==")
 for k, v in agg.items():
@@ -77,6 +91,6 @@ open(out, "w").write("\n".join(lines) + "\n")
 json.dump({"source": os.path.basename(out), "workload": "soup64k_4k_p6",
            "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, one run each; FETCH_SIZE x 2 KiB "
                    "(128-byte reads count as 64 on gfx950), WRITE_SIZE x 1 KiB; per launch",
-           "kernels": traffic},
+           "frame": frame, "kernels": traffic},
           open(os.path.join(os.path.dirname(out), "hbm_traffic_per_launch.json"), "w"), indent=1)
 print("\n".join(lines))
