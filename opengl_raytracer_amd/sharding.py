@@ -70,6 +70,15 @@ class _Streams:
         import contextlib
         return torch.cuda.stream(self.streams[i]) if self.bound else contextlib.nullcontext()
 
+    def follow(self):
+        """Every renderer's stream waits for the stream that is current (work the caller enqueued there on
+        buffers the renderers are about to overwrite: the gather of the last batch)."""
+        if self.bound:
+            cur = torch.cuda.current_stream(self.device)
+            for s in self.streams:
+                if s != cur:
+                    s.wait_stream(cur)
+
     def wait(self):
         """The stream that is current waits for every renderer's stream."""
         if self.bound:
@@ -122,7 +131,9 @@ class TileShardedFrame:
 
     def render(self, passes):
         """Renders this rank's tiles and gathers the frame on rank 0 (returns it there, else None).
-        With several renderers the frame is complete once wait() (or a device synchronize) has returned."""
+        With several renderers the frame is complete once wait() (or a device synchronize) has returned, and
+        its tensor is written again len(renderers) calls later: a caller that reads it on a stream of its own
+        finishes before then."""
         i = self.turn
         self.turn = (self.turn + 1) % len(self.rs)
         r, local = self.rs[i], self.locals[i]
@@ -165,7 +176,9 @@ class FrameBatch:
             self.gathered = [torch.zeros_like(self.local) for _ in range(self.world)]
 
     def render(self, passes):
-        # this rank's views go to the renderers in turn (a renderer's next view waits for its last one only)
+        # this rank's views go to the renderers in turn (a renderer's next view waits for its last one only);
+        # none of them starts before the gather of the last batch, which reads the tensor they write, is done
+        self.streams.follow()
         for j, k in enumerate(self.mine):
             i = j % len(self.rs)
             r = self.rs[i]
