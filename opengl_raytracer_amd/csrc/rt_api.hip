@@ -1443,6 +1443,7 @@ extern "C" int rt_intersect(rt_ctx *c)
         const int *list = nullptr, *count = nullptr;
         const int n_upper = c->n_rays; // the live rays are counted on the device; the host does not wait for it
         int n_slot = -1;
+        bool fresh_in_kernel = false;
         // a few hundred triangles are streamed through the per-pair filter faster than their groups
         // are swept
         // (the group sweeps queue pairs as triangle * 2048 + ray in 32 bits: larger meshes take it too)
@@ -1453,11 +1454,15 @@ extern "C" int rt_intersect(rt_ctx *c)
             // fresh rays: all live, all through camera_pos; visited in pixel-tile order
             if (int r = refresh_camera_recs(c)) return r;
             list = c->perm_d;
-            hipLaunchKernelGGL(intersect_setup_kernel, dim3(list_blocks(n_upper, BLOCK)), dim3(BLOCK), 0, c->stream,
-                               c->rays, list, count, n_upper, c->job, c->scratch.best, 1,
-                               shared_origin(c, c->cam.pos, 1.0f), (unsigned int *)nullptr, (unsigned int *)nullptr,
-                               (int *)nullptr, c->walk_count_d);
-            HIPCHK(c, hipGetLastError());
+            // (with the direction cells the traversal kernel sets its rays up in registers: no set-up kernel)
+            fresh_in_kernel = use_grid(c);
+            if (!fresh_in_kernel) {
+                hipLaunchKernelGGL(intersect_setup_kernel, dim3(list_blocks(n_upper, BLOCK)), dim3(BLOCK), 0, c->stream,
+                                   c->rays, list, count, n_upper, c->job, c->scratch.best, 1,
+                                   shared_origin(c, c->cam.pos, 1.0f), (unsigned int *)nullptr, (unsigned int *)nullptr,
+                                   (int *)nullptr, c->walk_count_d);
+                HIPCHK(c, hipGetLastError());
+            }
         } else {
             // (zero already when the last stage call to finish was an rt_color, whose last kernel saw to it)
             if (!c->count_clean[0]) HIPCHK(c, hipMemsetAsync(c->count_d, 0, sizeof(int), c->stream));
@@ -1511,6 +1516,10 @@ extern "C" int rt_intersect(rt_ctx *c)
         if (clustered) {
             if (int r = launch_traverse_clustered(c, p, n_upper, n_slot, sorted)) return r;
         } else if (shared && use_grid(c)) {
+            if (fresh_in_kernel) {
+                p.fresh_perm = c->perm_d;
+                p.fresh_rays = c->rays;
+            }
             if (int r = launch_traverse_grid(c, p, n_upper, n_slot, 0, false, 1)) return r;
         } else if (int r = launch_traverse(c, p, n_upper, n_slot, shared ? 1 : 0, false, 1)) {
             return r;
@@ -1518,7 +1527,7 @@ extern "C" int rt_intersect(rt_ctx *c)
         hipLaunchKernelGGL(intersect_finish_kernel, dim3(list_blocks(n_upper, BLOCK)), dim3(BLOCK), 0, c->stream,
                            c->rays, list, count, n_upper, c->job, c->scratch.best, c->verts, c->num_tris, c->cam,
                            c->depth, c->counters_d, c->count_d + 1,
-                           n_slot >= 0 ? c->klog_n_d + n_slot : (int *)nullptr);
+                           n_slot >= 0 ? c->klog_n_d + n_slot : (int *)nullptr, fresh_in_kernel ? 1 : 0);
         HIPCHK(c, hipGetLastError());
         c->count_clean[1] = true;
     }

@@ -241,16 +241,23 @@ struct Job {            // the ray a traversal launch traces, exactly as the ref
 };
 
 // fills job.b* and job.g for a ray with origin o and direction d (sign: see TraverseParams::dir_sign)
-__device__ __forceinline__ void prepare_shared(const Job &job, int slot, v3 o, v3 d, const float *origin,
-                                               const float *center, float radius, float reach_max, float sign)
+__device__ __forceinline__ void shared_direction(v3 o, v3 d, const float *origin, const float *center, float radius,
+                                                 float reach_max, float sign, float &bx, float &by, float &bz, float &g)
 {
     const float oo[3] = {o.x, o.y, o.z};
     const float reach = rtf::reach_shared(origin, oo, center, radius);
     const float inv = sign / sqrtf(rtx::dot(d, d));
-    const float bx = d.x * inv, by = d.y * inv, bz = d.z * inv;
-    const float g = rtf::dir_scale(reach, bx, by, bz);
+    bx = d.x * inv; by = d.y * inv; bz = d.z * inv;
+    const float gs = rtf::dir_scale(reach, bx, by, bz);
+    g = (reach <= reach_max) ? gs : -gs;
+}
+__device__ __forceinline__ void prepare_shared(const Job &job, int slot, v3 o, v3 d, const float *origin,
+                                               const float *center, float radius, float reach_max, float sign)
+{
+    float bx, by, bz, g;
+    shared_direction(o, d, origin, center, radius, reach_max, sign, bx, by, bz, g);
     job.bx[slot] = bx; job.by[slot] = by; job.bz[slot] = bz;
-    job.g[slot] = (reach <= reach_max) ? g : -g;
+    job.g[slot] = g;
 }
 
 // fills job.b* and job.g for an arbitrary ray (clustered traversal): unit direction, and the
@@ -646,6 +653,11 @@ struct TraverseParams {
     rtv::Grid vox;
     const unsigned int *vox_off;
     const int *vox_entries;
+    // traverse_grid_kernel<false> over rays fresh from raygen (fresh_perm != nullptr): slot s is ray
+    // fresh_perm[s], read from the ray planes and set up in registers (rayintersect_cs.glsl:12 and what
+    // prepare_shared() forms) -- no set-up kernel, no job planes; every slot's best is stored, not merged
+    const int *fresh_perm;
+    RaySoA fresh_rays;
     // walks that traverse_voxel_kernel hands over to traverse_voxel_long_kernel: (slot, parameter), their number
     int *walk_slot;
     float *walk_t;
@@ -1429,7 +1441,21 @@ __global__ __launch_bounds__(BLOCK) void traverse_grid_kernel(TraverseParams p)
     float hx = qn, hy = qn, hz = qn, g = qn;
     unsigned int cell = 0;
     if (valid && ANYHIT && p.occ[sl] != 0) valid = false; // already decided (tmax not finite)
-    if (valid) {
+    const bool fresh = !ANYHIT && p.fresh_perm != nullptr;
+    if (valid && fresh) {
+        const int i = p.fresh_perm[sl];
+        const RaySoA &r = p.fresh_rays;
+        v3 o = rtx::V(r.ox[i], r.oy[i], r.oz[i]);
+        const v3 d = rtx::V(r.dx[i], r.dy[i], r.dz[i]);
+        o = rtx::add(o, rtx::muls(d, 0.001f)); // r.origin = r.origin + r.dir * 0.001
+        float bx, by, bz;
+        shared_direction(o, d, p.origin, p.center, p.radius, p.reach_max, p.dir_sign, bx, by, bz, g);
+        const float gg = fabsf(g);
+        hx = bx * gg; hy = by * gg; hz = bz * gg;
+        cell = rtg::oct_cell(bx, by, bz, p.grid_bits);
+        ray_o[lane] = make_float4(o.x, o.y, o.z, 0.0f);
+        ray_d[lane] = make_float4(d.x, d.y, d.z, 0.0f);
+    } else if (valid) {
         const float bx = p.job.bx[sl], by = p.job.by[sl], bz = p.job.bz[sl];
         g = p.job.g[sl];
         const float gg = fabsf(g);
@@ -1553,7 +1579,8 @@ __global__ __launch_bounds__(BLOCK) void traverse_grid_kernel(TraverseParams p)
         if (occl[lane] != 0) p.occ[sl] = 1;
     } else {
         const unsigned long long key = best[lane];
-        if (key != BEST_NONE) atomicMin(&p.best[sl], key);
+        if (fresh) p.best[sl] = key; // the slot's only writer, and nobody set it up
+        else if (key != BEST_NONE) atomicMin(&p.best[sl], key);
     }
 }
 
@@ -2606,7 +2633,7 @@ __global__ __launch_bounds__(BLOCK) void intersect_finish_kernel(RaySoA r, const
                                                                  const rt_vertex *__restrict__ verts, int num_tris,
                                                                  Camera cam, float *__restrict__ depth,
                                                                  unsigned long long *counters, int *zero_this,
-                                                                 int *n_out)
+                                                                 int *n_out, int fresh)
 {
     const int n = count ? *count : n_fixed;
     if (blockIdx.x == 0 && threadIdx.x == 0) add_counter(counters, C_CH_RAYS, (unsigned long long)n);
@@ -2615,8 +2642,14 @@ __global__ __launch_bounds__(BLOCK) void intersect_finish_kernel(RaySoA r, const
     if (zero_this && blockIdx.x == 0 && threadIdx.x == 0) *zero_this = 0;
     RT_FOR_EACH_SLOT(slot, n) {
     const int i = list ? list[slot] : slot;
-    const v3 o = rtx::V(job.ox[slot], job.oy[slot], job.oz[slot]);
-    const v3 d = rtx::V(job.dx[slot], job.dy[slot], job.dz[slot]);
+    v3 o, d;
+    if (fresh) { // rays nobody set up: the traced ray is formed from the ray itself, as the traversal formed it
+        d = rtx::V(r.dx[i], r.dy[i], r.dz[i]);
+        o = rtx::add(rtx::V(r.ox[i], r.oy[i], r.oz[i]), rtx::muls(d, 0.001f));
+    } else {
+        o = rtx::V(job.ox[slot], job.oy[slot], job.oz[slot]);
+        d = rtx::V(job.dx[slot], job.dy[slot], job.dz[slot]);
+    }
     const unsigned long long key = best[slot];
     float tb = __uint_as_float((unsigned int)(key >> 32));
     int id = (int)(unsigned int)(key & 0xffffffffull);
