@@ -1519,16 +1519,20 @@ extern "C" int rt_intersect(rt_ctx *c)
             if (fresh_in_kernel) {
                 p.fresh_perm = c->perm_d;
                 p.fresh_rays = c->rays;
+                p.fresh_depth = c->depth;
+                p.fresh_zero = c->count_d + 1;
             }
             if (int r = launch_traverse_grid(c, p, n_upper, n_slot, 0, false, 1)) return r;
         } else if (int r = launch_traverse(c, p, n_upper, n_slot, shared ? 1 : 0, false, 1)) {
             return r;
         }
-        hipLaunchKernelGGL(intersect_finish_kernel, dim3(list_blocks(n_upper, BLOCK)), dim3(BLOCK), 0, c->stream,
-                           c->rays, list, count, n_upper, c->job, c->scratch.best, c->verts, c->num_tris, c->cam,
-                           c->depth, c->counters_d, c->count_d + 1,
-                           n_slot >= 0 ? c->klog_n_d + n_slot : (int *)nullptr, fresh_in_kernel ? 1 : 0);
-        HIPCHK(c, hipGetLastError());
+        if (!fresh_in_kernel) { // (fresh rays are finished by the traversal kernel that set them up)
+            hipLaunchKernelGGL(intersect_finish_kernel, dim3(list_blocks(n_upper, BLOCK)), dim3(BLOCK), 0, c->stream,
+                               c->rays, list, count, n_upper, c->job, c->scratch.best, c->verts, c->num_tris, c->cam,
+                               c->depth, c->counters_d, c->count_d + 1,
+                               n_slot >= 0 ? c->klog_n_d + n_slot : (int *)nullptr);
+            HIPCHK(c, hipGetLastError());
+        }
         c->count_clean[1] = true;
     }
     c->hits_follow_pixels = c->rays_share_camera_origin;

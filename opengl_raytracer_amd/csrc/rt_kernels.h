@@ -312,6 +312,55 @@ __device__ __forceinline__ v3 vpos(const rt_vertex *__restrict__ v, int i)
 }
 
 // ---------------------------------------------------------------------------
+// intersect, part 3 of 3, for one ray: the two spheres (trace.glsl:164-183), the normal of the winning
+// primitive, and rayintersect_cs.glsl:16-33.  (o, d): the ray as it was traced (origin already offset by
+// dir * 0.001); key: the closest triangle hit, (t bits, index), BEST_NONE for none.  The triangle normal
+// depends only on the winning triangle, so it is formed once here instead of on every improvement inside
+// the loop.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void intersect_finish_slot(const RaySoA &r, int i, v3 o, v3 d, unsigned long long key,
+                                                      const rt_vertex *__restrict__ verts, int num_tris,
+                                                      const float *cam_pos, float *__restrict__ depth)
+{
+    float tb = __uint_as_float((unsigned int)(key >> 32));
+    int id = (int)(unsigned int)(key & 0xffffffffull);
+    int kind = (tb < INFINITY) ? 1 : 0; // 0 none, 1 triangle, 2 sphere
+    v3 nrm = rtx::V(0.0f, 0.0f, 0.0f);
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        float ts;
+        if (rtx::ray_sphere(o, d, rtx::sphere_center(s), rtx::sphere_radius(s), ts)) {
+            if (ts > 0.0f && ts < tb) {
+                tb = ts;
+                id = num_tris + s;
+                kind = 2;
+                v3 pt = rtx::add(o, rtx::muls(d, tb));
+                nrm = rtx::normalize(rtx::sub(pt, rtx::sphere_center(s)));
+            }
+        }
+    }
+    if (kind == 1) {
+        const v3 X = vpos(verts, 3 * id), Y = vpos(verts, 3 * id + 1), Z = vpos(verts, 3 * id + 2);
+        nrm = rtx::normalize(rtx::cross(rtx::sub(X, Z), rtx::sub(Y, Z)));
+    } else if (kind == 0) {
+        nrm = rtx::V(r.nx[i], r.ny[i], r.nz[i]); // a miss keeps the old normal
+    }
+    v3 ob = rtx::sub(o, rtx::muls(d, 0.001f));
+    if (isinf(tb)) id = -2;
+    ob = rtx::add(ob, rtx::muls(d, tb));
+    const v3 dn = rtx::sub(d, rtx::muls(nrm, 2.0f * rtx::dot(d, nrm)));
+    r.ox[i] = ob.x; r.oy[i] = ob.y; r.oz[i] = ob.z;
+    r.dx[i] = dn.x; r.dy[i] = dn.y; r.dz[i] = dn.z;
+    r.t[i] = tb;
+    r.id[i] = id;
+    if (kind != 0) {
+        r.nx[i] = nrm.x; r.ny[i] = nrm.y; r.nz[i] = nrm.z;
+        r.cx[i] = 0.0f; r.cy[i] = 0.0f; r.cz[i] = (kind == 2) ? 1.0f : 0.0f;
+    }
+    depth[i] = rtx::distance3(ob, rtx::V(cam_pos[0], cam_pos[1], cam_pos[2]));
+}
+
+// ---------------------------------------------------------------------------
 // intersect, part 1 of 3  ("OpenGL Raytracer/rayintersect_cs.glsl":6-12)
 // ---------------------------------------------------------------------------
 
@@ -655,9 +704,12 @@ struct TraverseParams {
     const int *vox_entries;
     // traverse_grid_kernel<false> over rays fresh from raygen (fresh_perm != nullptr): slot s is ray
     // fresh_perm[s], read from the ray planes and set up in registers (rayintersect_cs.glsl:12 and what
-    // prepare_shared() forms) -- no set-up kernel, no job planes; every slot's best is stored, not merged
+    // prepare_shared() forms) -- no set-up kernel, no job planes, no merge of the slots' best hits
+    // ... and the kernel finishes them too (intersect_finish_slot: spheres, normal, the new ray, depth)
     const int *fresh_perm;
     RaySoA fresh_rays;
+    float *fresh_depth;
+    int *fresh_zero; // a counter to zero for the next stage call (intersect_finish_kernel's zero_this)
     // walks that traverse_voxel_kernel hands over to traverse_voxel_long_kernel: (slot, parameter), their number
     int *walk_slot;
     float *walk_t;
@@ -1573,14 +1625,24 @@ __global__ __launch_bounds__(BLOCK) void traverse_grid_kernel(TraverseParams p)
         add_counter(p.counters, ANYHIT ? C_SH_SLOW : C_CH_SLOW, n_slow);
         add_counter(p.counters, ANYHIT ? C_SH_PAIRS : C_CH_PAIRS,
                     (unsigned long long)min(R, n - s0) * (unsigned long long)p.num_tris);
+        if (fresh) { // intersect_finish_kernel's bookkeeping
+            add_counter(p.counters, C_CH_RAYS, (unsigned long long)min(R, n - s0));
+            if (s0 == 0 && p.fresh_zero) *p.fresh_zero = 0;
+        }
     }
     if (!valid) return;
     if (ANYHIT) {
         if (occl[lane] != 0) p.occ[sl] = 1;
     } else {
         const unsigned long long key = best[lane];
-        if (fresh) p.best[sl] = key; // the slot's only writer, and nobody set it up
-        else if (key != BEST_NONE) atomicMin(&p.best[sl], key);
+        if (fresh) {
+            // the slot's only wavefront: the hit is final, and the ray is finished here
+            const float4 ro = ray_o[lane], rd = ray_d[lane];
+            intersect_finish_slot(p.fresh_rays, p.fresh_perm[sl], rtx::V(ro.x, ro.y, ro.z), rtx::V(rd.x, rd.y, rd.z), key,
+                                  p.verts, p.num_tris, p.origin, p.fresh_depth);
+        } else if (key != BEST_NONE) {
+            atomicMin(&p.best[sl], key);
+        }
     }
 }
 
@@ -2633,7 +2695,7 @@ __global__ __launch_bounds__(BLOCK) void intersect_finish_kernel(RaySoA r, const
                                                                  const rt_vertex *__restrict__ verts, int num_tris,
                                                                  Camera cam, float *__restrict__ depth,
                                                                  unsigned long long *counters, int *zero_this,
-                                                                 int *n_out, int fresh)
+                                                                 int *n_out)
 {
     const int n = count ? *count : n_fixed;
     if (blockIdx.x == 0 && threadIdx.x == 0) add_counter(counters, C_CH_RAYS, (unsigned long long)n);
@@ -2642,51 +2704,9 @@ __global__ __launch_bounds__(BLOCK) void intersect_finish_kernel(RaySoA r, const
     if (zero_this && blockIdx.x == 0 && threadIdx.x == 0) *zero_this = 0;
     RT_FOR_EACH_SLOT(slot, n) {
     const int i = list ? list[slot] : slot;
-    v3 o, d;
-    if (fresh) { // rays nobody set up: the traced ray is formed from the ray itself, as the traversal formed it
-        d = rtx::V(r.dx[i], r.dy[i], r.dz[i]);
-        o = rtx::add(rtx::V(r.ox[i], r.oy[i], r.oz[i]), rtx::muls(d, 0.001f));
-    } else {
-        o = rtx::V(job.ox[slot], job.oy[slot], job.oz[slot]);
-        d = rtx::V(job.dx[slot], job.dy[slot], job.dz[slot]);
-    }
-    const unsigned long long key = best[slot];
-    float tb = __uint_as_float((unsigned int)(key >> 32));
-    int id = (int)(unsigned int)(key & 0xffffffffull);
-    int kind = (tb < INFINITY) ? 1 : 0; // 0 none, 1 triangle, 2 sphere
-    v3 nrm = rtx::V(0.0f, 0.0f, 0.0f);
-#pragma unroll
-    for (int s = 0; s < 2; s++) {
-        float ts;
-        if (rtx::ray_sphere(o, d, rtx::sphere_center(s), rtx::sphere_radius(s), ts)) {
-            if (ts > 0.0f && ts < tb) {
-                tb = ts;
-                id = num_tris + s;
-                kind = 2;
-                v3 pt = rtx::add(o, rtx::muls(d, tb));
-                nrm = rtx::normalize(rtx::sub(pt, rtx::sphere_center(s)));
-            }
-        }
-    }
-    if (kind == 1) {
-        const v3 X = vpos(verts, 3 * id), Y = vpos(verts, 3 * id + 1), Z = vpos(verts, 3 * id + 2);
-        nrm = rtx::normalize(rtx::cross(rtx::sub(X, Z), rtx::sub(Y, Z)));
-    } else if (kind == 0) {
-        nrm = rtx::V(r.nx[i], r.ny[i], r.nz[i]); // a miss keeps the old normal
-    }
-    v3 ob = rtx::sub(o, rtx::muls(d, 0.001f));
-    if (isinf(tb)) id = -2;
-    ob = rtx::add(ob, rtx::muls(d, tb));
-    const v3 dn = rtx::sub(d, rtx::muls(nrm, 2.0f * rtx::dot(d, nrm)));
-    r.ox[i] = ob.x; r.oy[i] = ob.y; r.oz[i] = ob.z;
-    r.dx[i] = dn.x; r.dy[i] = dn.y; r.dz[i] = dn.z;
-    r.t[i] = tb;
-    r.id[i] = id;
-    if (kind != 0) {
-        r.nx[i] = nrm.x; r.ny[i] = nrm.y; r.nz[i] = nrm.z;
-        r.cx[i] = 0.0f; r.cy[i] = 0.0f; r.cz[i] = (kind == 2) ? 1.0f : 0.0f;
-    }
-    depth[i] = rtx::distance3(ob, rtx::V(cam.pos[0], cam.pos[1], cam.pos[2]));
+    const v3 o = rtx::V(job.ox[slot], job.oy[slot], job.oz[slot]);
+    const v3 d = rtx::V(job.dx[slot], job.dy[slot], job.dz[slot]);
+    intersect_finish_slot(r, i, o, d, best[slot], verts, num_tris, cam.pos, depth);
     }
 }
 
