@@ -16,6 +16,11 @@ Two ways to shard (--sharding):
   batch  every rank renders whole frames: the 64-view workload deals its fixed set of views over the
          ranks ("strong", its default); a single-frame workload renders one frame per rank ("weak").
 
+Frames in flight (--frames-in-flight, default 3): every rank renders with that many contexts, which take the
+frames (views) of the sequence in turn on streams of their own, so that the kernel chains of consecutive
+frames overlap on the GPU; a step is still one frame (one batch of views), the time is the wall time of the
+K steps.  After the timed region one context alone renders a few more frames for the per-kernel figures.
+
 value = rays actually traced (closest-hit rays entering traversal + shadow rays traced, summed over
 passes and ranks) per second of wall time, in Mrays/s.  Rays that missed everything are dead (the
 reference skips them in intersect; in color they provably shade to the background grey, so no
