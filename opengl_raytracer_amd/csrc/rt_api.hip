@@ -131,6 +131,7 @@ struct rt_ctx {
     // direction cells of the band sweep: lists of member records, per mesh
     unsigned int *band_off = nullptr;
     int *band_entries = nullptr;
+    bool band_cells_pending = false; // rt_set_mesh left them to the first clustered bounce pass
 
     uint32_t *tex = nullptr;
     int tex_w = 0, tex_h = 0;
@@ -602,6 +603,7 @@ extern "C" int rt_set_mesh(rt_ctx *c, const rt_vertex *vertices, int num_vertice
     (void)hipFree(c->vox_entries_d); c->vox_entries_d = nullptr;
     (void)hipFree(c->band_off); c->band_off = nullptr;
     (void)hipFree(c->band_entries); c->band_entries = nullptr;
+    c->band_cells_pending = false;
     (void)hipFree(c->slot_views_d); c->slot_views_d = nullptr;
     c->num_vertices = num_vertices;
     c->num_tris = num_vertices / 3;
@@ -708,7 +710,9 @@ extern "C" int rt_set_mesh(rt_ctx *c, const rt_vertex *vertices, int num_vertice
             HIPCHK(c, hipStreamSynchronize(c->stream)); // vs goes out of scope
         }
         HIPCHK(c, hipStreamSynchronize(c->stream)); // the host vectors go out of scope
-        if (int r = build_band_cells(c)) return r;
+        // (the band sweep's lists are built by the first bounce pass that wants them: a host that only traces
+        // fresh rays and shadow rays never pays for them -- 12 ms and 300 MB at 64K triangles)
+        c->band_cells_pending = true;
     }
     c->have_mesh = true;
     c->camera_recs_dirty = true;
@@ -1450,6 +1454,11 @@ extern "C" int rt_intersect(rt_ctx *c)
         const bool clustered = !shared && c->trace_mode == RT_TRACE_CLUSTERED &&
                                c->num_tris >= c->cluster_min_tris && c->num_tris < (1 << 21);
         const bool sorted = clustered && n_upper >= c->sort_min_rays && c->num_ngroups >= 64;
+        if (clustered && c->band_cells_pending) {
+            // the first bounce pass on this mesh: the direction cells of the band sweep (waits for their size)
+            c->band_cells_pending = false;
+            if (int r = build_band_cells(c)) return r;
+        }
         if (shared) {
             // fresh rays: all live, all through camera_pos; visited in pixel-tile order
             if (int r = refresh_camera_recs(c)) return r;
