@@ -504,7 +504,7 @@ def test_bench_collectives_rehearsed_on_one_rank(workload):
     def run(*flags):
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", "3", "--warmup", "1",
                "--no-cpu-baseline", "--no-kernel-rooflines", *flags]
-        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=110)
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
         assert p.returncode == 0, p.stderr[-3000:]
         return json.loads(p.stdout.strip().splitlines()[-1])
 
