@@ -17,6 +17,8 @@ a frame leaves most of a GPU idle between them.  Both classes therefore accept a
 of its own, so that the chains of consecutive frames overlap on the GPU.  A frame returned by
 render() is complete once its stream has been waited for (`wait()` does that for all of them).
 """
+import contextlib
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -67,7 +69,6 @@ class _Streams:
                 r.bind_stream(s.cuda_stream)
 
     def on(self, i):
-        import contextlib
         return torch.cuda.stream(self.streams[i]) if self.bound else contextlib.nullcontext()
 
     def follow(self):
