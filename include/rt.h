@@ -151,6 +151,9 @@ int rt_set_trace_mode(rt_ctx *ctx, int mode /* rt_trace_mode */);
  *   RT_OPT_BAND_LIST_MAX    the band sweep's per-cell lists are built only if they hold at most this
  *                           many entries in total (default and maximum 0xffffff00: list positions
  *                           are 32-bit); beyond it the streaming band sweep runs
+ *   RT_OPT_BAND_BUCKETS     each of those lists is split by the origin of the ray into G x G lists,
+ *                           G = 1, 2, 4, 8 or 16 (default 8): shorter lists to read per ray, about
+ *                           1.3 G times the memory; halved until RT_OPT_BAND_LIST_MAX is met
  *   RT_OPT_VOXEL_RES        cells along the longest axis of the grid in space that bounce rays walk,
  *                           1..128, or 0 = chosen from the number of triangles (default 0)
  *   RT_OPT_WALK_BUDGET      loop steps a wavefront of that walk spends, one ray per lane, before the walks
@@ -167,7 +170,7 @@ int rt_set_trace_mode(rt_ctx *ctx, int mode /* rt_trace_mode */);
  *                           reports its duration; 0 (default): the log's records carry ms = 0.  An event
  *                           between two kernels costs the stream about 5 us of idle time, which a frame
  *                           of some thirty traversal launches should not pay unasked
- * RT_OPT_GRID_BITS, RT_OPT_BAND_LIST_MAX and RT_OPT_VOXEL_RES decide what rt_set_mesh builds: after
+ * RT_OPT_GRID_BITS, RT_OPT_BAND_LIST_MAX, RT_OPT_BAND_BUCKETS and RT_OPT_VOXEL_RES decide what rt_set_mesh builds: after
  * setting one of them the context has no mesh until the next rt_set_mesh. */
 typedef enum rt_option {
     RT_OPT_SORT_MIN_RAYS    = 0,
@@ -179,7 +182,8 @@ typedef enum rt_option {
     RT_OPT_WALK_BUDGET      = 6,
     RT_OPT_FAIL_NEXT_STAGE  = 7,
     RT_OPT_MOVING_ORIGIN_LEVELS = 8,
-    RT_OPT_KERNEL_TIMING    = 9
+    RT_OPT_KERNEL_TIMING    = 9,
+    RT_OPT_BAND_BUCKETS     = 10
 } rt_option;
 int rt_set_option(rt_ctx *ctx, int option /* rt_option */, long long value);
 

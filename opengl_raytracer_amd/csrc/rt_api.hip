@@ -132,6 +132,11 @@ struct rt_ctx {
     unsigned int *band_off = nullptr;
     int *band_entries = nullptr;
     bool band_cells_pending = false; // rt_set_mesh left them to the first clustered bounce pass
+    void *bucket_frames_d = nullptr;  // rtg::BucketFrame of every finest direction cell
+    int band_buckets = 8;             // origin buckets per cell and axis asked for (rt_set_option)
+    int band_g = 1;                   // ... and built
+    double mesh_lo[3] = {0, 0, 0}, mesh_hi[3] = {0, 0, 0}; // bounding box of the mesh's finite vertices
+    unsigned long long band_total = 0; // entries on the lists
 
     uint32_t *tex = nullptr;
     int tex_w = 0, tex_h = 0;
@@ -297,6 +302,7 @@ static int upload_row_map(rt_ctx *c)
 static void free_grid_tables(rt_ctx *c)
 {
     (void)hipFree(c->cell_cones_d); c->cell_cones_d = nullptr;
+    (void)hipFree(c->bucket_frames_d); c->bucket_frames_d = nullptr;
     (void)hipFree(c->grid_count_d); c->grid_count_d = nullptr;
     (void)hipFree(c->scan_temp); c->scan_temp = nullptr;
     c->scan_temp_bytes = 0;
@@ -497,6 +503,7 @@ extern "C" void rt_destroy(rt_ctx *c)
     (void)hipFree(c->bin_temp_d);
     (void)hipFree(c->klog_n_d);
     (void)hipFree(c->cell_cones_d);
+    (void)hipFree(c->bucket_frames_d);
     (void)hipFree(c->grid_count_d);
     (void)hipFree(c->scan_temp);
     (void)hipFree(c->band_off);
@@ -544,28 +551,92 @@ static int build_band_cells(rt_ctx *c)
     const size_t ncells = (size_t)1 << (2 * c->grid_bits);
     const int members = c->num_ngroups * rtc::NGROUP;
     const dim3 grid((unsigned)(((long long)members * BUILD_TOP_CELLS + BLOCK - 1) / BLOCK));
-    HIPCHK(c, hipMalloc(&c->band_off, (ncells + 2) * sizeof(unsigned int)));
-    HIPCHK(c, hipMemsetAsync(c->grid_count_d, 0, (ncells + 2) * sizeof(unsigned int), c->stream));
-    hipLaunchKernelGGL((band_build_kernel<false>), grid, dim3(BLOCK), 0, c->stream,
-                       (const rtg::CellCone *)c->cell_cones_d, c->grid_bits, (const float4 *)c->nrec_d, members,
-                       c->grid_count_d, (const unsigned int *)nullptr, (int *)nullptr);
-    HIPCHK(c, hipGetLastError());
-    // List positions are 32-bit: the exact total decides.  Longer lists are not built, and the streaming
-    // band sweep (traverse_band_kernel / traverse_group_kernel) takes over.
-    unsigned long long total64 = 0;
-    if (int r = sum_counts(c, c->grid_count_d, ncells + 2, &total64)) return r;
-    if (total64 > c->band_list_max) {
-        (void)hipFree(c->band_off);
-        c->band_off = nullptr;
+    // The buckets tile the mesh's bounding box as each cell sees it.  Bounce rays start on the mesh, a
+    // step of 0.001 directions off it: inside the box with a little room.
+    (void)hipFree(c->bucket_frames_d); c->bucket_frames_d = nullptr;
+    if (c->band_buckets > 1) {
+        double lo[3], hi[3];
+        for (int a = 0; a < 3; a++) {
+            const double room = 0.004 + 1e-3 * (c->mesh_hi[a] - c->mesh_lo[a]) + 1e-5 * std::fabs((double)c->center[a]);
+            lo[a] = c->mesh_lo[a] - room - (double)c->center[a];
+            hi[a] = c->mesh_hi[a] + room - (double)c->center[a];
+        }
+        std::vector<rtg::CellCone> cc(ncells);
+        HIPCHK(c, hipMemcpy(cc.data(), (const rtg::CellCone *)c->cell_cones_d + rtg::level_offset(c->grid_bits),
+                            ncells * sizeof(rtg::CellCone), hipMemcpyDeviceToHost));
+        std::vector<rtg::BucketFrame> bf(ncells);
+        for (size_t i = 0; i < ncells; i++) rtg::bucket_frame(cc[i], lo, hi, &bf[i]);
+        HIPCHK(c, hipMalloc(&c->bucket_frames_d, ncells * sizeof(rtg::BucketFrame)));
+        HIPCHK(c, hipMemcpy(c->bucket_frames_d, bf.data(), ncells * sizeof(rtg::BucketFrame), hipMemcpyHostToDevice));
+    }
+    // Each cell's list is split into G x G origin buckets; if the lists would be longer than the
+    // positions can address (or than rt_set_option allows), with fewer buckets, down to one per cell.
+    for (int G = c->band_buckets; G >= 1; G /= 2) {
+        const size_t nkeys = ncells * (G > 1 ? (size_t)G * G + 1 : 1);
+        unsigned int *cnt = nullptr;
+        void *tmp = nullptr;
+        size_t tmp_bytes = 0;
+        auto drop = [&]() {
+            (void)hipFree(cnt);
+            (void)hipFree(tmp);
+        };
+        HIPCHK(c, hipMalloc(&cnt, (nkeys + 2) * sizeof(unsigned int)));
+        if (hipMalloc(&c->band_off, (nkeys + 2) * sizeof(unsigned int)) != hipSuccess) {
+            drop();
+            c->band_off = nullptr;
+            return fail(c, RT_ERR_HIP, "build_band_cells: out of device memory");
+        }
+        bool ok = hipMemsetAsync(cnt, 0, (nkeys + 2) * sizeof(unsigned int), c->stream) == hipSuccess;
+        if (ok) {
+            hipLaunchKernelGGL((band_build_kernel<false>), grid, dim3(BLOCK), 0, c->stream,
+                               (const rtg::CellCone *)c->cell_cones_d, c->grid_bits, (const float4 *)c->nrec_d, members,
+                               (const rtg::BucketFrame *)c->bucket_frames_d, G, c->center[0], c->center[1],
+                               c->center[2], cnt, (const unsigned int *)nullptr, (int *)nullptr);
+            ok = hipGetLastError() == hipSuccess;
+        }
+        // List positions are 32-bit: the exact total decides.
+        unsigned long long total64 = 0;
+        if (!ok || sum_counts(c, cnt, nkeys + 2, &total64) != RT_OK) {
+            drop();
+            (void)hipFree(c->band_off); c->band_off = nullptr;
+            return fail(c, RT_ERR_HIP, "build_band_cells: counting the lists failed");
+        }
+        if (total64 > c->band_list_max) {
+            drop();
+            (void)hipFree(c->band_off); c->band_off = nullptr;
+            continue; // fewer buckets; with one per cell still too long: the streaming band sweep
+                      // (traverse_band_kernel / traverse_group_kernel) takes over
+        }
+        ok = rocprim::exclusive_scan(nullptr, tmp_bytes, cnt, c->band_off, 0u, nkeys + 2,
+                                     rocprim::plus<unsigned int>(), c->stream) == hipSuccess &&
+             hipMalloc(&tmp, tmp_bytes + 256) == hipSuccess &&
+             rocprim::exclusive_scan(tmp, tmp_bytes, cnt, c->band_off, 0u, nkeys + 2, rocprim::plus<unsigned int>(),
+                                     c->stream) == hipSuccess &&
+             hipMemsetAsync(cnt, 0, (nkeys + 2) * sizeof(unsigned int), c->stream) == hipSuccess &&
+             hipMalloc(&c->band_entries, ((size_t)total64 + 64) * sizeof(int)) == hipSuccess;
+        if (ok) {
+            hipLaunchKernelGGL((band_build_kernel<true>), grid, dim3(BLOCK), 0, c->stream,
+                               (const rtg::CellCone *)c->cell_cones_d, c->grid_bits, (const float4 *)c->nrec_d, members,
+                               (const rtg::BucketFrame *)c->bucket_frames_d, G, c->center[0], c->center[1],
+                               c->center[2], cnt, (const unsigned int *)c->band_off, c->band_entries);
+            ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess;
+        }
+        drop();
+        if (!ok) {
+            (void)hipFree(c->band_off); c->band_off = nullptr;
+            (void)hipFree(c->band_entries); c->band_entries = nullptr;
+            return fail(c, RT_ERR_HIP, "build_band_cells: building the lists failed");
+        }
+        c->band_g = G;
+        c->band_total = total64;
+        if (getenv("RT_BAND_REPORT")) { // diagnostic: what was built
+            unsigned int e[2] = {0, 0};
+            (void)hipMemcpy(e, c->band_off + nkeys, sizeof e, hipMemcpyDeviceToHost);
+            fprintf(stderr, "band lists: %d x %d buckets per cell, %zu lists, %llu entries, %u of them on the list \"everywhere\"\n",
+                    G, G, nkeys, total64, e[1] - e[0]);
+        }
         return RT_OK;
     }
-    size_t total = 0;
-    if (int r = scan_cell_counts(c, c->band_off, &total)) return r;
-    HIPCHK(c, hipMalloc(&c->band_entries, (total + 64) * sizeof(int)));
-    hipLaunchKernelGGL((band_build_kernel<true>), grid, dim3(BLOCK), 0, c->stream,
-                       (const rtg::CellCone *)c->cell_cones_d, c->grid_bits, (const float4 *)c->nrec_d, members,
-                       c->grid_count_d, (const unsigned int *)c->band_off, c->band_entries);
-    HIPCHK(c, hipGetLastError());
     return RT_OK;
 }
 
@@ -632,6 +703,10 @@ extern "C" int rt_set_mesh(rt_ctx *c, const rt_vertex *vertices, int num_vertice
             if (first || v > hi[a]) hi[a] = v;
         }
         first = false;
+    }
+    for (int a = 0; a < 3; a++) {
+        c->mesh_lo[a] = first ? 0.0 : lo[a];
+        c->mesh_hi[a] = first ? 0.0 : hi[a];
     }
     // the two spheres of trace.glsl:159-162 belong to every scene: rays start on them too
     static const double sph[2][4] = {{0.0, -0.7, 2.0, 0.5}, {-2.0, 0.0, 0.0, 0.2}};
@@ -833,6 +908,11 @@ extern "C" int rt_set_option(rt_ctx *c, int option, long long value)
         if (value < 0 || value > 0xffffff00ll) break;
         c->band_list_max = (unsigned long long)value;
         c->have_mesh = false; // the lists are built by rt_set_mesh
+        return RT_OK;
+    case RT_OPT_BAND_BUCKETS:
+        if (value != 1 && value != 2 && value != 4 && value != 8 && value != 16) break;
+        c->band_buckets = (int)value;
+        c->have_mesh = false; // the lists are built for one bucket count
         return RT_OK;
     case RT_OPT_FAIL_NEXT_STAGE:
         c->fail_next_stage = value != 0;
@@ -1150,6 +1230,9 @@ static int launch_traverse_clustered(rt_ctx *c, TraverseParams p, int n_upper, i
     if (sorted) a.alist = c->sort_slots; // rays grouped by direction share cells / groups; any order gives the same result
     if (c->band_entries) {
         a.band_off = c->band_off;
+        a.band_g = c->band_g;
+        a.band_cx = c->center[0]; a.band_cy = c->center[1]; a.band_cz = c->center[2];
+        a.bucket_frames = (const rtg::BucketFrame *)c->bucket_frames_d;
         a.band_entries = c->band_entries;
         a.grid_bits = c->grid_bits;
         a.rays_per_wave = 0; // from the list's length, on the device

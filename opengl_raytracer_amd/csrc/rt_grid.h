@@ -277,4 +277,118 @@ RT_HD uint32_t oct_cell_folded(float x, float y, float z, int bits)
 }
 RT_HD bool cell_reaches_upper_hemisphere(const CellCone &cc) { return cc.a[2] + cc.psi >= 0.0; }
 
+// Origin buckets of the band sweep's direction cells.  A member's slab |n2 . o - kappa'| < 1 is a thin
+// plate in space, and for the cells whose directions its band holds the plate's normal is close to
+// perpendicular to the cell's axis A: seen along A the plate is a strip.  Each cell's list is therefore
+// split by where a ray's origin falls on the plane across A: with q = o - centre written in a frame
+// (u, v, A) of the cell, the rectangle that the mesh's bounding box projects to is cut into G x G
+// buckets, and a member is listed in the buckets its strip can reach.  With n2 = a u + b v + c A:
+//     n2 . o - kappa' = k0 + a q.u + b q.v + c q.A,     k0 = n2 . centre - kappa',
+// so for an origin in the bucket around (qu, qv) (half sides hu, hv) with q.A within ha of qa
+//     |n2 . o - kappa'| >= |k0 + a qu + b qv + c qa| - |a| hu - |b| hv - |c| ha,
+// and the member is listed unless that is >= 1 + margin.  The margin covers the float evaluation of the
+// slab test (three fma's on terms up to |n2| (|centre| + |q|) + |kappa'|), the float frame and bucket
+// index of a ray against the doubles here (each half side is widened by 2^-10 of a side), and a frame
+// that is orthonormal to rounding only.  A ray whose origin is outside the box (it starts on one of the
+// two spheres of the scene, say) has no bucket: it reads the cell's whole list, which is kept as well.
+struct BucketFrame {
+    float u[3], v[3], a[3];
+    float u0, v0, a0;          // the box in the frame: [u0, u0 + ulen] x [v0, v0 + vlen] x [a0, a0 + alen]
+    float ulen, vlen, alen;
+    float pad;
+};
+// box_lo, box_hi: the mesh's bounding box relative to the centre, with room for where bounce rays start
+RT_HD void bucket_frame(const CellCone &cc, const double box_lo[3], const double box_hi[3], BucketFrame *f)
+{
+    const double *A = cc.a;
+    // the coordinate axis furthest from A, made perpendicular to it
+    const int k = fabs(A[0]) <= fabs(A[1]) ? (fabs(A[0]) <= fabs(A[2]) ? 0 : 2) : (fabs(A[1]) <= fabs(A[2]) ? 1 : 2);
+    double u[3] = {-A[k] * A[0], -A[k] * A[1], -A[k] * A[2]};
+    u[k] += 1.0;
+    const double ul = sqrt(rtf::dot3d(u, u));
+    for (int i = 0; i < 3; i++) u[i] /= ul;
+    const double v[3] = {A[1] * u[2] - A[2] * u[1], A[2] * u[0] - A[0] * u[2], A[0] * u[1] - A[1] * u[0]};
+    for (int i = 0; i < 3; i++) {
+        f->u[i] = (float)u[i];
+        f->v[i] = (float)v[i];
+        f->a[i] = (float)A[i];
+    }
+    // the box's extent along each axis of the (float) frame
+    const float *ax[3] = {f->u, f->v, f->a};
+    double lo[3], len[3];
+    for (int j = 0; j < 3; j++) {
+        double l = 0.0, h = 0.0;
+        for (int i = 0; i < 3; i++) {
+            const double e = (double)ax[j][i];
+            l += e >= 0.0 ? e * box_lo[i] : e * box_hi[i];
+            h += e >= 0.0 ? e * box_hi[i] : e * box_lo[i];
+        }
+        lo[j] = l;
+        len[j] = h - l > 1e-30 ? h - l : 1e-30;
+    }
+    f->u0 = (float)lo[0]; f->v0 = (float)lo[1]; f->a0 = (float)lo[2];
+    f->ulen = (float)len[0]; f->vlen = (float)len[1]; f->alen = (float)len[2];
+    f->pad = 0.0f;
+}
+// the bucket (iy * G + ix) of an origin (relative to the centre), or -1 outside the box
+RT_HD int bucket_of(const BucketFrame &f, float qx, float qy, float qz, int G)
+{
+    const float qu = f.u[0] * qx + f.u[1] * qy + f.u[2] * qz - f.u0;
+    const float qv = f.v[0] * qx + f.v[1] * qy + f.v[2] * qz - f.v0;
+    const float qa = f.a[0] * qx + f.a[1] * qy + f.a[2] * qz - f.a0;
+    if (!(qu >= 0.0f && qu <= f.ulen && qv >= 0.0f && qv <= f.vlen && qa >= 0.0f && qa <= f.alen)) return -1; // (NaN: none)
+    int ix = (int)(qu * ((float)G / f.ulen)), iy = (int)(qv * ((float)G / f.vlen));
+    ix = ix < 0 ? 0 : (ix > G - 1 ? G - 1 : ix);
+    iy = iy < 0 ? 0 : (iy > G - 1 ? G - 1 : iy);
+    return iy * G + ix;
+}
+struct BucketStrip {
+    double k, a, b, bound, u0, v0, su, sv; // |k + a qu + b qv| < bound; bucket (ix, iy) is centred at (u0 + (ix + .5) su, ..)
+};
+RT_HD BucketStrip bucket_strip(const BucketFrame &f, float n2x, float n2y, float n2z, float kappa, const float center[3],
+                               int G)
+{
+    const double n[3] = {(double)n2x, (double)n2y, (double)n2z};
+    const double ctr[3] = {(double)center[0], (double)center[1], (double)center[2]};
+    const double u[3] = {(double)f.u[0], (double)f.u[1], (double)f.u[2]};
+    const double v[3] = {(double)f.v[0], (double)f.v[1], (double)f.v[2]};
+    const double A[3] = {(double)f.a[0], (double)f.a[1], (double)f.a[2]};
+    BucketStrip s;
+    const double c = rtf::dot3d(n, A);
+    const double ha = 0.5 * (double)f.alen * (1.0 + 0.001953125);
+    s.k = rtf::dot3d(n, ctr) - (double)kappa + c * ((double)f.a0 + 0.5 * (double)f.alen);
+    s.a = rtf::dot3d(n, u);
+    s.b = rtf::dot3d(n, v);
+    s.u0 = (double)f.u0; s.v0 = (double)f.v0;
+    s.su = (double)f.ulen / (double)G;
+    s.sv = (double)f.vlen / (double)G;
+    const double nl = sqrt(rtf::dot3d(n, n)), cl = sqrt(rtf::dot3d(ctr, ctr));
+    const double reach = fabs(s.u0) + fabs(s.v0) + fabs((double)f.a0) + (double)f.ulen + (double)f.vlen + (double)f.alen;
+    const double margin = 1e-3 + 1e-6 * (nl * (cl + reach) + fabs((double)kappa));
+    const double wide = 0.5 + 0.0009765625;
+    s.bound = 1.0 + margin + fabs(c) * ha + fabs(s.a) * s.su * wide + fabs(s.b) * s.sv * wide;
+    return s;
+}
+RT_HD bool bucket_meets_strip(const BucketStrip &s, int ix, int iy)
+{
+    const double qu = s.u0 + ((double)ix + 0.5) * s.su, qv = s.v0 + ((double)iy + 0.5) * s.sv;
+    return fabs(s.k + s.a * qu + s.b * qv) < s.bound;
+}
+// the buckets iy of column ix that can meet the strip lie in [*lo, *hi] (maybe none: *lo > *hi); the
+// range is generous by a bucket on each side, bucket_meets_strip() decides
+RT_HD void bucket_column_range(const BucketStrip &s, int ix, int G, int *lo, int *hi)
+{
+    *lo = 0;
+    *hi = G - 1;
+    const double base = s.k + s.a * (s.u0 + ((double)ix + 0.5) * s.su);
+    const double span = fabs(s.b) * s.sv; // what one bucket up or down changes
+    if (!(span * (double)G > 1e-9 * (fabs(base) + fabs(s.b * s.v0) + s.bound))) return; // the strip runs along the column
+    // |base + b (v0 + (iy + .5) sv)| < bound  <=>  iy + .5 within bound/span of -(base + b v0) / (b sv)
+    const double mid = -(base + s.b * s.v0) / (s.b * s.sv) - 0.5, half = s.bound / span;
+    const double l = mid - half - 1.0, h = mid + half + 1.0;
+    if (l > 0.0) *lo = l < (double)G ? (int)l : G;
+    if (h < (double)(G - 1)) *hi = h >= 0.0 ? (int)h + 1 : -1;
+    if (*hi > G - 1) *hi = G - 1;
+}
+
 } // namespace rtg

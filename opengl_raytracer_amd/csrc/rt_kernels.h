@@ -689,6 +689,10 @@ struct TraverseParams {
     int num_slots;
     // direction cells of the band sweep (traverse_bandcell_kernel): lists of member records
     const unsigned int *band_off;
+    // ... and its band_g x band_g origin buckets (rt_grid.h): list cell * (band_g^2 + 1) + bucket
+    int band_g;
+    float band_cx, band_cy, band_cz;
+    const rtg::BucketFrame *bucket_frames;
     const int *band_entries;
     int rays_per_wave;            // direction-cell kernels: 64, or fewer for small launches (see their comments)
     // band sweeps of arbitrary rays (traverse_group_kernel, traverse_band_kernel, traverse_bandcell_kernel)
@@ -1989,11 +1993,16 @@ __global__ __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(BLOCK) v
 // records (positions in nrecs) whose band shares a direction with the cell.  One thread per member
 // walks the cells from the coarsest level down, as grid_build_kernel does.  A member whose band is
 // every direction goes on the list "everywhere" (index num_cells); padding and never-accepted
-// members on none.  FILL as in grid_build_kernel.
+// members on none.  With G > 1 a cell has G x G lists more, by the origin of the ray (rt_grid.h,
+// "Origin buckets"): list cell * (G^2 + 1) + bucket holds the members whose slab reaches the bucket,
+// list cell * (G^2 + 1) + G^2 the whole cell; the list "everywhere" is index num_cells * (G^2 + 1).
+// FILL as in grid_build_kernel.
 // ---------------------------------------------------------------------------
 template <bool FILL>
 __global__ __launch_bounds__(BLOCK) void band_build_kernel(const rtg::CellCone *__restrict__ cells, int bits,
                                                            const float4 *__restrict__ nrecs, int num_members,
+                                                           const rtg::BucketFrame *__restrict__ frames, int G,
+                                                           float cx, float cy, float cz,
                                                            unsigned int *__restrict__ count,
                                                            const unsigned int *__restrict__ off,
                                                            int *__restrict__ entries)
@@ -2007,12 +2016,14 @@ __global__ __launch_bounds__(BLOCK) void band_build_kernel(const rtg::CellCone *
     const float4 m1 = nrecs[2 * pos], m2 = nrecs[2 * pos + 1];
     if (__float_as_int(m2.w) < 0 || m1.w == 2.0f) return; // padding / never accepted
     const unsigned int num_cells = 1u << (2 * bits);
-    auto emit = [&](unsigned int cell) {
-        const unsigned int k = atomicAdd(&count[cell], 1u);
-        if (FILL) entries[off[cell] + k] = pos;
+    const unsigned int per_cell = G > 1 ? (unsigned int)(G * G + 1) : 1u;
+    const float ctr[3] = {cx, cy, cz};
+    auto emit = [&](unsigned int key) {
+        const unsigned int k = atomicAdd(&count[key], 1u);
+        if (FILL) entries[off[key] + k] = pos;
     };
     if (m1.x == 0.0f && m1.y == 0.0f && m1.z == 0.0f) { // its band is every direction
-        if (top == 0) emit(num_cells);
+        if (top == 0) emit(num_cells * per_cell);
         return;
     }
     unsigned int (*stack)[BLOCK] = stack_all; // [depth][thread]: (level << 24) | cell
@@ -2026,7 +2037,16 @@ __global__ __launch_bounds__(BLOCK) void band_build_kernel(const rtg::CellCone *
         const rtg::CellCone cc = cells[rtg::level_offset(level) + cell];
         if (!rtg::cell_reaches_upper_hemisphere(cc) || !rtg::cell_meets_band(cc, m1.x, m1.y, m1.z, 1.0f)) continue;
         if (level == bits) {
-            emit(cell);
+            emit(cell * per_cell + per_cell - 1u);
+            if (G > 1) {
+                const rtg::BucketStrip st = rtg::bucket_strip(frames[cell], m2.x, m2.y, m2.z, m1.w, ctr, G);
+                for (int ix = 0; ix < G; ix++) {
+                    int lo, hi;
+                    rtg::bucket_column_range(st, ix, G, &lo, &hi);
+                    for (int iy = lo; iy <= hi; iy++)
+                        if (rtg::bucket_meets_strip(st, ix, iy)) emit(cell * per_cell + (unsigned int)(iy * G + ix));
+                }
+            }
         } else {
             for (unsigned int k = 0; k < 4; k++) stack[sp++][tx] = ((unsigned int)(level + 1) << 24) | (cell * 4 + k);
         }
@@ -2063,12 +2083,18 @@ __global__ __launch_bounds__(BLOCK) void traverse_bandcell_kernel(TraverseParams
     const int sl = valid ? (p.alist ? p.alist[s] : s) : 0;
     const float qn = __int_as_float(0x7fc00000);
     float ox = qn, oy = qn, oz = qn, bx = qn, by = qn, bz = qn, g = qn;
-    unsigned int cell = 0;
+    unsigned int cell = 0; // the list of the ray: its direction's cell, and its origin's bucket there
+    const unsigned int per_cell = p.band_g > 1 ? (unsigned int)(p.band_g * p.band_g + 1) : 1u;
     if (valid) {
         ox = p.job.ox[sl]; oy = p.job.oy[sl]; oz = p.job.oz[sl];
         bx = p.job.bx[sl]; by = p.job.by[sl]; bz = p.job.bz[sl];
         g = p.job.g[sl];
         cell = rtg::oct_cell_folded(bx, by, bz, p.grid_bits);
+        if (p.band_g > 1) { // (an origin outside the buckets: the cell's whole list)
+            const int bucket = rtg::bucket_of(p.bucket_frames[cell], ox - p.band_cx, oy - p.band_cy, oz - p.band_cz,
+                                              p.band_g);
+            cell = cell * per_cell + (bucket < 0 ? per_cell - 1u : (unsigned int)bucket);
+        }
         ray_o[lane] = make_float4(ox, oy, oz, fabsf(g));
         ray_d[lane] = make_float4(p.job.dx[sl], p.job.dy[sl], p.job.dz[sl], 0.0f);
     }
@@ -2143,7 +2169,7 @@ __global__ __launch_bounds__(BLOCK) void traverse_bandcell_kernel(TraverseParams
 
     unsigned long long remaining = __builtin_amdgcn_ballot_w64(valid && !wild);
     // the members that are on every cell's list follow the cell's own
-    const unsigned int every = 1u << (2 * p.grid_bits);
+    const unsigned int every = (1u << (2 * p.grid_bits)) * per_cell;
     const unsigned int eoff = p.band_off[every];
     const int ecnt = (int)(p.band_off[every + 1] - eoff);
     // The rays of the wavefront, cell by cell, each cell's list 64 members a step.  A step is two loads

@@ -436,11 +436,15 @@ extern "C" void fm_check_grid(int n_tris, const float *verts, int n_rays, const 
 // a member is on the list of the ray's (folded) cell iff its band meets the cell and every coarser
 // cell above it, all of which reach the hemisphere z >= 0; members whose band is every direction are
 // on the list "everywhere".  A pair the member test  max(|n1.b|, |n2.o - kappa'|) < 1  lets through
-// must be listed.
+// must be listed.  With G > 1 the cell's list is split into G x G origin buckets (rt_grid.h): the member
+// must be on the list of the ray's bucket; a ray whose origin has no bucket reads the cell's whole list.
+// Every bucket a member is listed in must also lie inside bucket_column_range(), which is what the build
+// kernel loops over.
 // stats: [0] pairs [1] listed [2] member test passes [3] violations (passes && !listed)
+//        [4] pairs of rays without a bucket [5] listed buckets outside their column's range
 // ---------------------------------------------------------------------------------------------
 extern "C" void fm_check_band_cells(int n_tris, const float *verts, int n_rays, const float *org, const float *dir,
-                                    const float *center, float radius, int bits, long long *stats)
+                                    const float *center, float radius, int bits, int G, long long *stats)
 {
     rtc::ClusterSet cs;
     std::vector<rt_vertex> v((size_t)n_tris * 3);
@@ -452,6 +456,27 @@ extern "C" void fm_check_band_cells(int n_tris, const float *verts, int n_rays, 
     const int levels = bits - rtg::MIN_LEVEL + 1;
     std::vector<rtg::CellCone> cc((size_t)n_rays * levels);
     std::vector<float> bb((size_t)n_rays * 3);
+    // the mesh's box relative to the centre, with room, as build_band_cells() in rt_api.hip forms it
+    double blo[3] = {0, 0, 0}, bhi[3] = {0, 0, 0};
+    {
+        bool first = true;
+        for (int i = 0; i < n_tris * 3; i++) {
+            const float *q = verts + 3 * i;
+            if (!(std::isfinite(q[0]) && std::isfinite(q[1]) && std::isfinite(q[2]))) continue;
+            for (int a = 0; a < 3; a++) {
+                if (first || q[a] < blo[a]) blo[a] = q[a];
+                if (first || q[a] > bhi[a]) bhi[a] = q[a];
+            }
+            first = false;
+        }
+        for (int a = 0; a < 3; a++) {
+            const double room = 0.004 + 1e-3 * (bhi[a] - blo[a]) + 1e-5 * std::fabs((double)center[a]);
+            blo[a] = blo[a] - room - (double)center[a];
+            bhi[a] = bhi[a] + room - (double)center[a];
+        }
+    }
+    std::vector<rtg::BucketFrame> frame(n_rays);
+    std::vector<int> bucket(n_rays, 0);
     for (int i = 0; i < n_rays; i++) {
         const float *d = dir + 3 * i;
         const float inv = 1.0f / sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
@@ -459,10 +484,15 @@ extern "C" void fm_check_band_cells(int n_tris, const float *verts, int n_rays, 
         const uint32_t cell = rtg::oct_cell_folded(bb[3 * i], bb[3 * i + 1], bb[3 * i + 2], bits);
         for (int l = rtg::MIN_LEVEL; l <= bits; l++)
             rtg::make_cell_cone(cell >> (2 * (bits - l)), l, &cc[(size_t)i * levels + (l - rtg::MIN_LEVEL)]);
+        if (G > 1) {
+            const float *o = org + 3 * i;
+            rtg::bucket_frame(cc[(size_t)i * levels + levels - 1], blo, bhi, &frame[i]);
+            bucket[i] = rtg::bucket_of(frame[i], o[0] - center[0], o[1] - center[1], o[2] - center[2], G);
+        }
     }
     const size_t members = cs.nmembers.size();
-    long long pairs = 0, listed_n = 0, pass_n = 0, bad = 0;
-#pragma omp parallel for reduction(+ : pairs, listed_n, pass_n, bad) schedule(static)
+    long long pairs = 0, listed_n = 0, pass_n = 0, bad = 0, no_bucket = 0, off_range = 0;
+#pragma omp parallel for reduction(+ : pairs, listed_n, pass_n, bad, no_bucket, off_range) schedule(static)
     for (size_t pos = 0; pos < members; pos++) {
         const float *m1 = &cs.nrecs[pos * 8], *m2 = m1 + 4;
         int32_t tri;
@@ -472,12 +502,23 @@ extern "C" void fm_check_band_cells(int n_tris, const float *verts, int n_rays, 
         for (int i = 0; i < n_rays; i++) {
             const float *o = org + 3 * i;
             const float bx = bb[3 * i], by = bb[3 * i + 1], bz = bb[3 * i + 2];
+            no_bucket += bucket[i] < 0;
             bool listed = true;
-            if (!everywhere)
+            if (!everywhere) {
                 for (int l = 0; l < levels && listed; l++) {
                     const rtg::CellCone &c = cc[(size_t)i * levels + l];
                     listed = rtg::cell_reaches_upper_hemisphere(c) && rtg::cell_meets_band(c, m1[0], m1[1], m1[2], 1.0f);
                 }
+                if (listed && G > 1 && bucket[i] >= 0) {
+                    const rtg::BucketStrip st = rtg::bucket_strip(frame[i], m2[0], m2[1], m2[2], m1[3], center, G);
+                    listed = rtg::bucket_meets_strip(st, bucket[i] % G, bucket[i] / G);
+                    if (listed) {
+                        int lo, hi;
+                        rtg::bucket_column_range(st, bucket[i] % G, G, &lo, &hi);
+                        off_range += !(bucket[i] / G >= lo && bucket[i] / G <= hi);
+                    }
+                }
+            }
             const float t0 = fmaf(m1[2], bz, fmaf(m1[1], by, m1[0] * bx));
             const float h0 = fmaf(m2[2], o[2], fmaf(m2[1], o[1], fmaf(m2[0], o[0], -m1[3])));
             const bool pass = fmaxf(fabsf(t0), fabsf(h0)) < 1.0f;
@@ -487,7 +528,7 @@ extern "C" void fm_check_band_cells(int n_tris, const float *verts, int n_rays, 
             bad += (pass && !listed);
         }
     }
-    stats[0] = pairs; stats[1] = listed_n; stats[2] = pass_n; stats[3] = bad;
+    stats[0] = pairs; stats[1] = listed_n; stats[2] = pass_n; stats[3] = bad; stats[4] = no_bucket; stats[5] = off_range;
 }
 
 // ---------------------------------------------------------------------------------------------

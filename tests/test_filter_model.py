@@ -687,17 +687,17 @@ def test_direction_cells_light_near_surfaces_and_wild_rays(fm):
     assert st["bad"] == 0 and st["wild"] == ld.shape[0], st
 
 
-def run_band_cells(fm, tris, org, dirs, bits=8):
+def run_band_cells(fm, tris, org, dirs, bits=8, buckets=1):
     c, r = bounding_sphere(tris)
-    stats = (C.c_longlong * 4)()
+    stats = (C.c_longlong * 6)()
     tris = np.ascontiguousarray(tris, dtype=f32)
     org = np.ascontiguousarray(org, dtype=f32)
     dirs = np.ascontiguousarray(dirs, dtype=f32)
     fm.fm_check_band_cells.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
-                                       C.c_int, C.c_void_p]
+                                       C.c_int, C.c_int, C.c_void_p]
     fm.fm_check_band_cells(tris.shape[0], tris.ctypes.data, org.shape[0], org.ctypes.data, dirs.ctypes.data,
-                           c.ctypes.data, r, bits, stats)
-    return dict(zip(["pairs", "listed", "passes", "bad"], list(stats)))
+                           c.ctypes.data, r, bits, buckets, stats)
+    return dict(zip(["pairs", "listed", "passes", "bad", "no_bucket", "off_range"], list(stats)))
 
 
 def plane_rays_per_triangle(rs, tris, n_per=4, tilt=(-9, -4)):
@@ -737,6 +737,46 @@ def test_band_cells_hold_every_member_a_ray_is_inside(fm, bits):
     assert st["passes"] > 1000, st
     if bits >= 8:
         assert st["listed"] < 0.5 * st["pairs"], st   # the slivers among the nasty triangles are in every band
+
+
+@pytest.mark.parametrize("buckets,offset", [(2, (0, 0, 0)), (8, (0, 0, 0)), (8, (40, -25, 3)), (16, (0.3, 0, 0))])
+def test_band_cell_origin_buckets_hold_every_member_a_ray_is_inside(fm, buckets, offset):
+    """The lists split by the origin of the ray: every member whose band and slab test a ray passes is on
+    the list of the ray's direction cell AND origin bucket (rays that start on the mesh, as bounce rays do,
+    in and a hair off the planes of triangles; a mesh far from the world's origin too)."""
+    rs = np.random.RandomState(131 + buckets)
+    tris = np.concatenate([tris_random(rs, 1200, 1.0, 0.05, offset), tris_nasty(rs, 300, 1.0) + np.asarray(offset, f32)])
+    tris = tris.astype(f32)
+    org, dirs = plane_rays_per_triangle(rs, tris, n_per=3)
+    # origins pulled back onto (or next to) the triangles: inside the bounding sphere, where the buckets are
+    t = np.repeat(tris[None], 3, 0).reshape(-1, 3, 3)[:org.shape[0]].astype(np.float64)
+    w = rs.dirichlet([1, 1, 1], size=org.shape[0])[:, :, None]
+    on = (t * w).sum(1)
+    ok = np.isfinite(on).all(1) & np.isfinite(dirs).all(1)
+    org2 = np.where(rs.uniform(size=(org.shape[0], 1)) < 0.7, on, 0.5 * (on + org)).astype(f32)
+    org2, dirs2 = org2[ok], dirs[ok]
+    # and rays between triangles: start on one, aimed along another's plane
+    perm = rs.permutation(org2.shape[0])
+    org3 = org2[perm]
+    org_all = np.concatenate([org2, org3]); dirs_all = np.concatenate([dirs2, dirs2])
+    st = run_band_cells(fm, tris, org_all, dirs_all, bits=8, buckets=buckets)
+    assert st["bad"] == 0 and st["off_range"] == 0, st
+    assert st["passes"] > 1000, st
+    assert 0 < st["no_bucket"] < 0.3 * st["pairs"], st    # some rays start off the mesh: they read whole lists
+    whole = run_band_cells(fm, tris, org_all, dirs_all, bits=8, buckets=1)
+    assert st["listed"] <= whole["listed"], (st, whole)
+    if buckets >= 8:
+        # (not by much on this mesh: most of its listings are slivers whose slab is wide; on a mesh of
+        # ordinary triangles the buckets shorten the lists several times over)
+        assert st["listed"] < whole["listed"], (st, whole)
+        tris = tris_random(rs, 2500, 1.0, 0.03, offset)
+        on = (tris.astype(np.float64) * rs.dirichlet([1, 1, 1], size=tris.shape[0])[:, :, None]).sum(1).astype(f32)
+        _, dirs = plane_rays_per_triangle(rs, tris, n_per=1)
+        org = on[rs.permutation(on.shape[0])][:dirs.shape[0]]
+        st = run_band_cells(fm, tris, org, dirs, bits=9, buckets=buckets)
+        whole = run_band_cells(fm, tris, org, dirs, bits=9, buckets=1)
+        assert st["bad"] == 0 and st["off_range"] == 0 and st["passes"] > 300, st
+        assert st["listed"] < 0.4 * whole["listed"], (st, whole)
 
 
 # -- the cells of a walk by rank (traverse_voxel_long_kernel) against the cells found step by step -----------

@@ -220,6 +220,38 @@ def test_streaming_band_sweep_when_lists_are_not_built(rt, oracle_mod, sort_min)
         assert forms[0] == 3 and 2 in forms[1:], forms
 
 
+# -- the band lists split by the origin of the ray -----------------------------------------------------
+@pytest.mark.parametrize("opts,built", [({"band_buckets": 1}, 1), ({"band_buckets": 2}, 2), ({"band_buckets": 16}, 16),
+                                        ({"band_buckets": 16, "band_list_max": 40_000_000}, None)],
+                         ids=["one_list_per_cell", "2x2", "16x16", "halved_to_fit"])
+def test_band_lists_by_origin_bucket(rt, oracle_mod, monkeypatch, capfd, opts, built):
+    """RT_OPT_BAND_BUCKETS: every bucket count renders the oracle's frame, rays that start off the mesh
+    (on the scene's two spheres, which this camera sees) included; a limit on the lists' length halves
+    the bucket count until they fit.  What was built is read from the library's report."""
+    import re
+    from opengl_raytracer_amd import scenes
+    monkeypatch.setenv("RT_BAND_REPORT", "1")
+    w, h = 320, 200
+    mesh = scenes.concat_meshes(scenes.triangle_soup(7000, seed=23, extent=0.8, size=0.09),
+                                scenes.quad_grid(12, 12, origin=(-1.4, -1.2, 2.8), du=(2.8, 0, 0), dv=(0, 2.4, 0.2)))
+    g, c = rt.RayTracer(w, h, options=opts), oracle_mod.Oracle(w, h, threads=16)
+    with g:
+        for o in (g, c):
+            o.set_mesh(mesh)
+            o.set_texture(scenes.noise_texture(64, 64))
+            o.set_lights(scenes.default_lights(), 2)
+            o.set_camera(*scenes.look_at_camera((-0.6, 0.1, -3.2), (-0.3, -0.1, 0.5)))
+        g.render(4); c.render(4)
+        same("band buckets %r" % (opts,), g, c)
+        report = re.findall(r"band lists: (\d+) x \d+ buckets per cell, \d+ lists, (\d+) entries", capfd.readouterr().err)
+        assert len(report) == 1, report
+        got, entries = int(report[0][0]), int(report[0][1])
+        if built is not None:
+            assert got == built, report
+        else:
+            assert 1 <= got < 16 and entries <= opts["band_list_max"], report
+
+
 # -- a camera moved between raygen and intersect ------------------------------------------------------
 @pytest.mark.parametrize("mode,name", MODES[:2], ids=[m[1] for m in MODES[:2]])
 def test_camera_moved_after_raygen(rt, oracle_mod, mode, name):
