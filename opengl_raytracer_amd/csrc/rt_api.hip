@@ -11,7 +11,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <memory>
 #include <mutex>
+#include <tuple>
 #include <string>
 #include <vector>
 
@@ -58,6 +61,40 @@ static hipError_t static_stage_address(int dev, void **out)
 struct EventPair {
     hipEvent_t a, b;
 };
+
+// The band sweep's lists of one mesh on one device.  They depend on the mesh, the resolution of the
+// direction cells and the bucket count only, are read-only once built, and are the largest thing a context
+// holds: the contexts of a process that hold the same mesh on the same device (several, when frames are
+// kept in flight) share one copy.  The registry keeps weak references; the lists go with their last context.
+struct BandLists {
+    int device = 0;
+    unsigned int *off = nullptr;
+    int *entries = nullptr;
+    void *frames = nullptr;
+    int g = 1;
+    unsigned long long total = 0;
+    ~BandLists()
+    {
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        (void)hipSetDevice(device);
+        (void)hipFree(off);
+        (void)hipFree(entries);
+        (void)hipFree(frames);
+        (void)hipSetDevice(cur);
+    }
+};
+struct BandKey {
+    int device, num_vertices, grid_bits, buckets;
+    unsigned long long limit, h1, h2; // (two 64-bit hashes of the vertex array)
+    bool operator<(const BandKey &o) const
+    {
+        return std::tie(device, num_vertices, grid_bits, buckets, limit, h1, h2) <
+               std::tie(o.device, o.num_vertices, o.grid_bits, o.buckets, o.limit, o.h1, o.h2);
+    }
+};
+static std::mutex g_band_mutex;
+static std::map<BandKey, std::weak_ptr<BandLists>> g_band_cache;
 
 struct rt_ctx {
     int device = 0;
@@ -133,10 +170,12 @@ struct rt_ctx {
     int *band_entries = nullptr;
     bool band_cells_pending = false; // rt_set_mesh left them to the first clustered bounce pass
     void *bucket_frames_d = nullptr;  // rtg::BucketFrame of every finest direction cell
-    int band_buckets = 8;             // origin buckets per cell and axis asked for (rt_set_option)
+    int band_buckets = 0;             // origin buckets per cell and axis asked for (rt_set_option); 0: chosen here
     int band_g = 1;                   // ... and built
     double mesh_lo[3] = {0, 0, 0}, mesh_hi[3] = {0, 0, 0}; // bounding box of the mesh's finite vertices
     unsigned long long band_total = 0; // entries on the lists
+    std::shared_ptr<BandLists> band_shared; // owns band_off, band_entries and bucket_frames_d once they are built
+    unsigned long long mesh_hash[2] = {0, 0};
 
     uint32_t *tex = nullptr;
     int tex_w = 0, tex_h = 0;
@@ -299,10 +338,28 @@ static int upload_row_map(rt_ctx *c)
 
 // The tables of the direction cells that depend on the resolution only: the cells' bounding cones at
 // every level (one table for every origin), the per-cell counters and the scan's temporary storage.
+// Lets go of the band sweep's lists (the context's own half-built ones, or its share of built ones).
+static void drop_band_lists(rt_ctx *c)
+{
+    if (c->band_shared) {
+        std::lock_guard<std::mutex> lock(g_band_mutex);
+        c->band_shared.reset();
+        for (auto it = g_band_cache.begin(); it != g_band_cache.end();)
+            it = it->second.expired() ? g_band_cache.erase(it) : std::next(it);
+    } else {
+        (void)hipFree(c->band_off);
+        (void)hipFree(c->band_entries);
+        (void)hipFree(c->bucket_frames_d);
+    }
+    c->band_off = nullptr;
+    c->band_entries = nullptr;
+    c->bucket_frames_d = nullptr;
+}
+
 static void free_grid_tables(rt_ctx *c)
 {
     (void)hipFree(c->cell_cones_d); c->cell_cones_d = nullptr;
-    (void)hipFree(c->bucket_frames_d); c->bucket_frames_d = nullptr;
+    drop_band_lists(c); // (built for these cells)
     (void)hipFree(c->grid_count_d); c->grid_count_d = nullptr;
     (void)hipFree(c->scan_temp); c->scan_temp = nullptr;
     c->scan_temp_bytes = 0;
@@ -502,11 +559,9 @@ extern "C" void rt_destroy(rt_ctx *c)
     (void)hipFree(c->bin_temp_d);
     (void)hipFree(c->klog_n_d);
     (void)hipFree(c->cell_cones_d);
-    (void)hipFree(c->bucket_frames_d);
     (void)hipFree(c->grid_count_d);
     (void)hipFree(c->scan_temp);
-    (void)hipFree(c->band_off);
-    (void)hipFree(c->band_entries);
+    drop_band_lists(c);
     (void)hipFree(c->slot_views_d);
     (void)hipFree(c->build_count_d);
     (void)hipFree(c->build_keys_d);
@@ -552,8 +607,30 @@ static int build_band_cells(rt_ctx *c)
     const dim3 grid((unsigned)(((long long)members * BUILD_TOP_CELLS + BLOCK - 1) / BLOCK));
     // The buckets tile the mesh's bounding box as each cell sees it.  Bounce rays start on the mesh, a
     // step of 0.001 directions off it: inside the box with a little room.
-    (void)hipFree(c->bucket_frames_d); c->bucket_frames_d = nullptr;
-    if (c->band_buckets > 1) {
+    drop_band_lists(c);
+    // another context of this process may hold them already (the lock is kept while they are built, so
+    // that a context asking meanwhile waits and then shares them)
+    std::lock_guard<std::mutex> lock(g_band_mutex);
+    const unsigned long long limit =
+        c->band_buckets ? c->band_list_max : std::min<unsigned long long>(c->band_list_max, 1ull << 30);
+    const BandKey key{c->device, c->num_vertices, c->grid_bits, c->band_buckets, limit, c->mesh_hash[0], c->mesh_hash[1]};
+    {
+        auto it = g_band_cache.find(key);
+        std::shared_ptr<BandLists> held = it != g_band_cache.end() ? it->second.lock() : nullptr;
+        if (held) {
+            c->band_shared = held;
+            c->band_off = held->off;
+            c->band_entries = held->entries;
+            c->bucket_frames_d = held->frames;
+            c->band_g = held->g;
+            c->band_total = held->total;
+            if (getenv("RT_BAND_REPORT"))
+                fprintf(stderr, "band lists: shared with another context (%d x %d buckets per cell, %llu entries)\n",
+                        held->g, held->g, held->total);
+            return RT_OK;
+        }
+    }
+    if (c->band_buckets != 1) {
         double lo[3], hi[3];
         for (int a = 0; a < 3; a++) {
             const double room = 0.004 + 1e-3 * (c->mesh_hi[a] - c->mesh_lo[a]) + 1e-5 * std::fabs((double)c->center[a]);
@@ -570,7 +647,8 @@ static int build_band_cells(rt_ctx *c)
     }
     // Each cell's list is split into G x G origin buckets; if the lists would be longer than the
     // positions can address (or than rt_set_option allows), with fewer buckets, down to one per cell.
-    for (int G = c->band_buckets; G >= 1; G /= 2) {
+    // Left to choose, the context takes 8 x 8 and keeps the lists within 2^30 entries (4 GiB): `limit`.
+    for (int G = c->band_buckets ? c->band_buckets : 8; G >= 1; G /= 2) {
         const size_t nkeys = ncells * (G > 1 ? (size_t)G * G + 1 : 1);
         unsigned int *cnt = nullptr;
         void *tmp = nullptr;
@@ -600,11 +678,17 @@ static int build_band_cells(rt_ctx *c)
             (void)hipFree(c->band_off); c->band_off = nullptr;
             return fail(c, RT_ERR_HIP, "build_band_cells: counting the lists failed");
         }
-        if (total64 > c->band_list_max) {
+        if (total64 > limit) {
             drop();
             (void)hipFree(c->band_off); c->band_off = nullptr;
-            continue; // fewer buckets; with one per cell still too long: the streaming band sweep
-                      // (traverse_band_kernel / traverse_group_kernel) takes over
+            // fewer buckets (the lists' length is close to proportional to G: skip the counts that cannot
+            // fit); with one per cell still too long: the streaming band sweep (traverse_band_kernel /
+            // traverse_group_kernel) takes over
+            while (G > 2 && total64 / 2 > limit + limit / 4) {
+                G /= 2;
+                total64 /= 2;
+            }
+            continue;
         }
         ok = rocprim::exclusive_scan(nullptr, tmp_bytes, cnt, c->band_off, 0u, nkeys + 2,
                                      rocprim::plus<unsigned int>(), c->stream) == hipSuccess &&
@@ -628,6 +712,17 @@ static int build_band_cells(rt_ctx *c)
         }
         c->band_g = G;
         c->band_total = total64;
+        {
+            auto held = std::make_shared<BandLists>();
+            held->device = c->device;
+            held->off = c->band_off;
+            held->entries = c->band_entries;
+            held->frames = c->bucket_frames_d;
+            held->g = G;
+            held->total = total64;
+            c->band_shared = held;
+            g_band_cache[key] = held;
+        }
         if (getenv("RT_BAND_REPORT")) { // diagnostic: what was built
             unsigned int e[2] = {0, 0};
             (void)hipMemcpy(e, c->band_off + nkeys, sizeof e, hipMemcpyDeviceToHost);
@@ -671,12 +766,27 @@ extern "C" int rt_set_mesh(rt_ctx *c, const rt_vertex *vertices, int num_vertice
     c->num_ngroups = 0;
     (void)hipFree(c->vox_off_d); c->vox_off_d = nullptr;
     (void)hipFree(c->vox_entries_d); c->vox_entries_d = nullptr;
-    (void)hipFree(c->band_off); c->band_off = nullptr;
-    (void)hipFree(c->band_entries); c->band_entries = nullptr;
+    drop_band_lists(c);
     c->band_cells_pending = false;
     (void)hipFree(c->slot_views_d); c->slot_views_d = nullptr;
     c->num_vertices = num_vertices;
     c->num_tris = num_vertices / 3;
+    {
+        // identifies the mesh among the contexts of the process (see BandLists)
+        unsigned long long h1 = 0x243f6a8885a308d3ull, h2 = 0x13198a2e03707344ull;
+        const size_t words = (size_t)num_vertices * sizeof(rt_vertex) / 8;
+        const unsigned char *bytes = reinterpret_cast<const unsigned char *>(vertices);
+        for (size_t i = 0; i < words; i++) {
+            unsigned long long w;
+            memcpy(&w, bytes + 8 * i, 8);
+            h1 = (h1 ^ w) * 0x9e3779b97f4a7c15ull;
+            h1 = (h1 << 29) | (h1 >> 35);
+            h2 = (h2 + w) * 0xc2b2ae3d27d4eb4full;
+            h2 ^= h2 >> 31;
+        }
+        c->mesh_hash[0] = h1;
+        c->mesh_hash[1] = h2;
+    }
     // record arrays are padded to whole tiles so that a tile copy never leaves the allocation
     c->rec_stride = ((size_t)c->num_tris + TILE - 1) / TILE * TILE + TILE;
     HIPCHK(c, hipMalloc(&c->verts, ((size_t)num_vertices + 3) * sizeof(rt_vertex)));
@@ -909,7 +1019,7 @@ extern "C" int rt_set_option(rt_ctx *c, int option, long long value)
         c->have_mesh = false; // the lists are built by rt_set_mesh
         return RT_OK;
     case RT_OPT_BAND_BUCKETS:
-        if (value != 1 && value != 2 && value != 4 && value != 8 && value != 16) break;
+        if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 16) break;
         c->band_buckets = (int)value;
         c->have_mesh = false; // the lists are built for one bucket count
         return RT_OK;
@@ -938,8 +1048,7 @@ extern "C" int rt_set_option(rt_ctx *c, int option, long long value)
         if (int r = use_device(c)) return r;
         HIPCHK(c, hipStreamSynchronize(c->stream));
         free_grid_tables(c);
-        (void)hipFree(c->band_off); c->band_off = nullptr;
-        (void)hipFree(c->band_entries); c->band_entries = nullptr;
+        drop_band_lists(c);
         c->grid_bits = (int)value;
         c->have_mesh = false; // every list is built for one resolution
         c->camera_recs_dirty = c->light_recs_dirty = true;

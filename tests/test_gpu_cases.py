@@ -252,6 +252,63 @@ def test_band_lists_by_origin_bucket(rt, oracle_mod, monkeypatch, capfd, opts, b
             assert 1 <= got < 16 and entries <= opts["band_list_max"], report
 
 
+def test_band_lists_shared_by_contexts_with_the_same_mesh(rt, oracle_mod, monkeypatch, capfd):
+    """Contexts of one process that hold the same mesh on the same device (frames in flight) share one
+    copy of the band lists: the first bounce pass of the first context builds them, the others' find them;
+    a context with another mesh, or other options, builds its own; and once every holder is gone the next
+    context builds them again.  Every frame equals the oracle's."""
+    import re
+    from opengl_raytracer_amd import scenes
+    monkeypatch.setenv("RT_BAND_REPORT", "1")
+    w, h = 256, 160
+    mesh = scenes.triangle_soup(5000, seed=29, extent=0.9, size=0.08)
+    other = scenes.triangle_soup(5000, seed=30, extent=0.9, size=0.08)
+
+    def scene(o, m, eye):
+        o.set_mesh(m)
+        o.set_texture(scenes.noise_texture(32, 32))
+        o.set_lights(scenes.default_lights(), 1)
+        o.set_camera(*scenes.look_at_camera(eye, (0, 0, 0)))
+
+    def reports():
+        err = capfd.readouterr().err
+        return len(re.findall(r"band lists: \d+ x \d+ buckets per cell, \d+ lists", err)), err.count("band lists: shared")
+
+    eyes = [(0.2, 0.1, -2.6), (-0.4, 0.3, -2.4), (0.0, -0.5, -2.8)]
+    c = oracle_mod.Oracle(w, h, threads=16)
+    gs = [rt.RayTracer(w, h) for _ in eyes]
+    try:
+        for g, eye in zip(gs, eyes):
+            scene(g, mesh, eye)
+        for g in gs:                      # all three in flight before any is read
+            g.render(3)
+        for g, eye in zip(gs, eyes):
+            scene(c, mesh, eye); c.render(3)
+            same("shared band lists, eye %r" % (eye,), g, c)
+        assert reports() == (1, 2)
+        # another mesh in one of them: lists of its own; the other two keep theirs
+        scene(gs[1], other, eyes[1]); gs[1].render(3)
+        scene(c, other, eyes[1]); c.render(3)
+        same("a context with another mesh", gs[1], c)
+        assert reports() == (1, 0)
+        gs[0].render(3); scene(c, mesh, eyes[0]); c.render(3)
+        same("the first context after its neighbour changed meshes", gs[0], c)
+        # other options: lists of its own
+        with rt.RayTracer(w, h, options={"band_buckets": 2}) as g2:
+            scene(g2, mesh, eyes[2]); g2.render(3)
+            scene(c, mesh, eyes[2]); c.render(3)
+            same("a context with other bucket counts", g2, c)
+        assert reports() == (1, 0)
+    finally:
+        for g in gs:
+            g.close()
+    with rt.RayTracer(w, h) as g:         # every holder is gone: built again
+        scene(g, mesh, eyes[0]); g.render(3)
+        scene(c, mesh, eyes[0]); c.render(3)
+        same("after the lists were freed", g, c)
+    assert reports() == (1, 0)
+
+
 # -- a camera moved between raygen and intersect ------------------------------------------------------
 @pytest.mark.parametrize("mode,name", MODES[:2], ids=[m[1] for m in MODES[:2]])
 def test_camera_moved_after_raygen(rt, oracle_mod, mode, name):
