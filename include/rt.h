@@ -153,8 +153,8 @@ int rt_set_trace_mode(rt_ctx *ctx, int mode /* rt_trace_mode */);
  *                           are 32-bit); beyond it the streaming band sweep runs
  *   RT_OPT_BAND_BUCKETS     each of those lists is split by the origin of the ray into G x G lists,
  *                           G = 1, 2, 4, 8 or 16: shorter lists to read per ray, about 1.5 G times the
- *                           memory; halved until RT_OPT_BAND_LIST_MAX is met.  0 (default): 8, halved until
- *                           the lists hold at most 2^30 entries (4 GiB) as well
+ *                           memory; halved until RT_OPT_BAND_LIST_MAX is met.  0 (default): 16, halved until
+ *                           the lists hold at most 2^31 entries (8 GiB) as well
  *   RT_OPT_VOXEL_RES        cells along the longest axis of the grid in space that bounce rays walk,
  *                           1..128, or 0 = chosen from the number of triangles (default 0)
  *   RT_OPT_WALK_BUDGET      loop steps a wavefront of that walk spends, one ray per lane, before the walks

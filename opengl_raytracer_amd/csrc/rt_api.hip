@@ -586,7 +586,6 @@ extern "C" void rt_destroy(rt_ctx *c)
 }
 
 // Lists of the band sweep's direction cells, from the member records of the mesh: count, scan, fill.
-static int scan_cell_counts(rt_ctx *c, unsigned int *off, size_t *total);
 // *total = the sum of n 32-bit counts, in 64 bits (one stream sync)
 static int sum_counts(rt_ctx *c, const unsigned int *v, size_t n, unsigned long long *total)
 {
@@ -612,7 +611,7 @@ static int build_band_cells(rt_ctx *c)
     // that a context asking meanwhile waits and then shares them)
     std::lock_guard<std::mutex> lock(g_band_mutex);
     const unsigned long long limit =
-        c->band_buckets ? c->band_list_max : std::min<unsigned long long>(c->band_list_max, 1ull << 30);
+        c->band_buckets ? c->band_list_max : std::min<unsigned long long>(c->band_list_max, 1ull << 31);
     const BandKey key{c->device, c->num_vertices, c->grid_bits, c->band_buckets, limit, c->mesh_hash[0], c->mesh_hash[1]};
     {
         auto it = g_band_cache.find(key);
@@ -645,91 +644,114 @@ static int build_band_cells(rt_ctx *c)
         HIPCHK(c, hipMalloc(&c->bucket_frames_d, ncells * sizeof(rtg::BucketFrame)));
         HIPCHK(c, hipMemcpy(c->bucket_frames_d, bf.data(), ncells * sizeof(rtg::BucketFrame), hipMemcpyHostToDevice));
     }
-    // Each cell's list is split into G x G origin buckets; if the lists would be longer than the
-    // positions can address (or than rt_set_option allows), with fewer buckets, down to one per cell.
-    // Left to choose, the context takes 8 x 8 and keeps the lists within 2^30 entries (4 GiB): `limit`.
-    for (int G = c->band_buckets ? c->band_buckets : 8; G >= 1; G /= 2) {
-        const size_t nkeys = ncells * (G > 1 ? (size_t)G * G + 1 : 1);
-        unsigned int *cnt = nullptr;
-        void *tmp = nullptr;
-        size_t tmp_bytes = 0;
-        auto drop = [&]() {
-            (void)hipFree(cnt);
-            (void)hipFree(tmp);
-        };
-        HIPCHK(c, hipMalloc(&cnt, (nkeys + 2) * sizeof(unsigned int)));
-        if (hipMalloc(&c->band_off, (nkeys + 2) * sizeof(unsigned int)) != hipSuccess) {
-            drop();
-            c->band_off = nullptr;
-            return fail(c, RT_ERR_HIP, "build_band_cells: out of device memory");
+    // device buffers of the build, freed on every way out unless handed on
+    struct DevBuf {
+        void *p = nullptr;
+        ~DevBuf() { (void)hipFree(p); }
+        void *release()
+        {
+            void *q = p;
+            p = nullptr;
+            return q;
         }
-        bool ok = hipMemsetAsync(cnt, 0, (nkeys + 2) * sizeof(unsigned int), c->stream) == hipSuccess;
-        if (ok) {
-            hipLaunchKernelGGL((band_build_kernel<false>), grid, dim3(BLOCK), 0, c->stream,
-                               (const rtg::CellCone *)c->cell_cones_d, c->grid_bits, (const float4 *)c->nrec_d, members,
-                               (const rtg::BucketFrame *)c->bucket_frames_d, G, c->center[0], c->center[1],
-                               c->center[2], cnt, (const unsigned int *)nullptr, (int *)nullptr);
-            ok = hipGetLastError() == hipSuccess;
-        }
-        // List positions are 32-bit: the exact total decides.
-        unsigned long long total64 = 0;
-        if (!ok || sum_counts(c, cnt, nkeys + 2, &total64) != RT_OK) {
-            drop();
-            (void)hipFree(c->band_off); c->band_off = nullptr;
-            return fail(c, RT_ERR_HIP, "build_band_cells: counting the lists failed");
-        }
-        if (total64 > limit) {
-            drop();
-            (void)hipFree(c->band_off); c->band_off = nullptr;
-            // fewer buckets (the lists' length is close to proportional to G: skip the counts that cannot
-            // fit); with one per cell still too long: the streaming band sweep (traverse_band_kernel /
-            // traverse_group_kernel) takes over
-            while (G > 2 && total64 / 2 > limit + limit / 4) {
+    };
+    auto scan = [&](unsigned int *cnt, unsigned int *off, size_t n) { // off[] = exclusive scan of cnt[0 .. n)
+        DevBuf tmp;
+        size_t bytes = 0;
+        return rocprim::exclusive_scan(nullptr, bytes, cnt, off, 0u, n, rocprim::plus<unsigned int>(), c->stream) == hipSuccess &&
+               hipMalloc(&tmp.p, bytes + 256) == hipSuccess &&
+               rocprim::exclusive_scan(tmp.p, bytes, cnt, off, 0u, n, rocprim::plus<unsigned int>(), c->stream) == hipSuccess &&
+               hipStreamSynchronize(c->stream) == hipSuccess; // (tmp is freed on return)
+    };
+    // ---- one list per cell: count, scan, fill
+    DevBuf cnt1, off1, ent1;
+    unsigned long long total1 = 0;
+    HIPCHK(c, hipMalloc(&cnt1.p, (ncells + 2) * sizeof(unsigned int)));
+    HIPCHK(c, hipMalloc(&off1.p, (ncells + 2) * sizeof(unsigned int)));
+    HIPCHK(c, hipMemsetAsync(cnt1.p, 0, (ncells + 2) * sizeof(unsigned int), c->stream));
+    hipLaunchKernelGGL((band_build_kernel<false>), grid, dim3(BLOCK), 0, c->stream, (const rtg::CellCone *)c->cell_cones_d,
+                       c->grid_bits, (const float4 *)c->nrec_d, members, (unsigned int *)cnt1.p,
+                       (const unsigned int *)nullptr, (int *)nullptr);
+    HIPCHK(c, hipGetLastError());
+    // List positions are 32-bit: the exact total decides.  Lists too long even so are not built, and the
+    // streaming band sweep (traverse_band_kernel / traverse_group_kernel) takes over.
+    if (int r = sum_counts(c, (const unsigned int *)cnt1.p, ncells + 2, &total1)) return r;
+    if (total1 > limit) return RT_OK;
+    if (!scan((unsigned int *)cnt1.p, (unsigned int *)off1.p, ncells + 2))
+        return fail(c, RT_ERR_HIP, "build_band_cells: scanning the cells' counts failed");
+    HIPCHK(c, hipMemsetAsync(cnt1.p, 0, (ncells + 2) * sizeof(unsigned int), c->stream));
+    HIPCHK(c, hipMalloc(&ent1.p, ((size_t)total1 + 64) * sizeof(int)));
+    hipLaunchKernelGGL((band_build_kernel<true>), grid, dim3(BLOCK), 0, c->stream, (const rtg::CellCone *)c->cell_cones_d,
+                       c->grid_bits, (const float4 *)c->nrec_d, members, (unsigned int *)cnt1.p,
+                       (const unsigned int *)off1.p, (int *)ent1.p);
+    HIPCHK(c, hipGetLastError());
+    // ---- each cell's list split into G x G origin buckets (band_bucket_kernel): if the lists would be
+    // longer than the positions can address (or than rt_set_option allows), with fewer buckets, down to the
+    // one list per cell above.  Left to choose, the context takes 16 x 16 and keeps the lists within 2^31
+    // entries (8 GiB): `limit`.
+    int built_g = 1;
+    size_t nkeys = ncells;
+    unsigned long long total64 = total1;
+    for (int G = c->band_buckets ? c->band_buckets : 16; G > 1; G /= 2) {
+        const size_t nk = ncells * ((size_t)G * G + 1);
+        DevBuf cnt, off, ent;
+        unsigned long long total = 0;
+        HIPCHK(c, hipMalloc(&cnt.p, (nk + 2) * sizeof(unsigned int)));
+        HIPCHK(c, hipMalloc(&off.p, (nk + 2) * sizeof(unsigned int)));
+        HIPCHK(c, hipMemsetAsync((unsigned int *)cnt.p + nk, 0, 2 * sizeof(unsigned int), c->stream));
+        hipLaunchKernelGGL((band_bucket_kernel<false>), dim3((unsigned)ncells + 1), dim3(BLOCK), 0, c->stream,
+                           (const unsigned int *)off1.p, (const int *)ent1.p, c->grid_bits, (const float4 *)c->nrec_d,
+                           (const rtg::BucketFrame *)c->bucket_frames_d, G, c->center[0], c->center[1], c->center[2],
+                           (unsigned int *)cnt.p, (const unsigned int *)nullptr, (int *)nullptr);
+        HIPCHK(c, hipGetLastError());
+        if (int r = sum_counts(c, (const unsigned int *)cnt.p, nk + 2, &total)) return r;
+        if (total > limit) {
+            // (the lists' length is close to proportional to G: skip the counts that cannot fit)
+            while (G > 2 && total / 2 > limit + limit / 4) {
                 G /= 2;
-                total64 /= 2;
+                total /= 2;
             }
             continue;
         }
-        ok = rocprim::exclusive_scan(nullptr, tmp_bytes, cnt, c->band_off, 0u, nkeys + 2,
-                                     rocprim::plus<unsigned int>(), c->stream) == hipSuccess &&
-             hipMalloc(&tmp, tmp_bytes + 256) == hipSuccess &&
-             rocprim::exclusive_scan(tmp, tmp_bytes, cnt, c->band_off, 0u, nkeys + 2, rocprim::plus<unsigned int>(),
-                                     c->stream) == hipSuccess &&
-             hipMemsetAsync(cnt, 0, (nkeys + 2) * sizeof(unsigned int), c->stream) == hipSuccess &&
-             hipMalloc(&c->band_entries, ((size_t)total64 + 64) * sizeof(int)) == hipSuccess;
-        if (ok) {
-            hipLaunchKernelGGL((band_build_kernel<true>), grid, dim3(BLOCK), 0, c->stream,
-                               (const rtg::CellCone *)c->cell_cones_d, c->grid_bits, (const float4 *)c->nrec_d, members,
-                               (const rtg::BucketFrame *)c->bucket_frames_d, G, c->center[0], c->center[1],
-                               c->center[2], cnt, (const unsigned int *)c->band_off, c->band_entries);
-            ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess;
-        }
-        drop();
-        if (!ok) {
-            (void)hipFree(c->band_off); c->band_off = nullptr;
-            (void)hipFree(c->band_entries); c->band_entries = nullptr;
-            return fail(c, RT_ERR_HIP, "build_band_cells: building the lists failed");
-        }
-        c->band_g = G;
-        c->band_total = total64;
-        {
-            auto held = std::make_shared<BandLists>();
-            held->device = c->device;
-            held->off = c->band_off;
-            held->entries = c->band_entries;
-            held->frames = c->bucket_frames_d;
-            held->g = G;
-            held->total = total64;
-            c->band_shared = held;
-            g_band_cache[key] = held;
-        }
-        if (getenv("RT_BAND_REPORT")) { // diagnostic: what was built
-            unsigned int e[2] = {0, 0};
-            (void)hipMemcpy(e, c->band_off + nkeys, sizeof e, hipMemcpyDeviceToHost);
-            fprintf(stderr, "band lists: %d x %d buckets per cell, %zu lists, %llu entries, %u of them on the list \"everywhere\"\n",
-                    G, G, nkeys, total64, e[1] - e[0]);
-        }
-        return RT_OK;
+        if (!scan((unsigned int *)cnt.p, (unsigned int *)off.p, nk + 2))
+            return fail(c, RT_ERR_HIP, "build_band_cells: scanning the buckets' counts failed");
+        HIPCHK(c, hipMalloc(&ent.p, ((size_t)total + 64) * sizeof(int)));
+        hipLaunchKernelGGL((band_bucket_kernel<true>), dim3((unsigned)ncells + 1), dim3(BLOCK), 0, c->stream,
+                           (const unsigned int *)off1.p, (const int *)ent1.p, c->grid_bits, (const float4 *)c->nrec_d,
+                           (const rtg::BucketFrame *)c->bucket_frames_d, G, c->center[0], c->center[1], c->center[2],
+                           (unsigned int *)cnt.p, (const unsigned int *)off.p, (int *)ent.p);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->band_off = (unsigned int *)off.release();
+        c->band_entries = (int *)ent.release();
+        built_g = G;
+        nkeys = nk;
+        total64 = total;
+        break;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (built_g == 1) {
+        c->band_off = (unsigned int *)off1.release();
+        c->band_entries = (int *)ent1.release();
+    }
+    c->band_g = built_g;
+    c->band_total = total64;
+    {
+        auto held = std::make_shared<BandLists>();
+        held->device = c->device;
+        held->off = c->band_off;
+        held->entries = c->band_entries;
+        held->frames = c->bucket_frames_d;
+        held->g = built_g;
+        held->total = total64;
+        c->band_shared = held;
+        g_band_cache[key] = held;
+    }
+    if (getenv("RT_BAND_REPORT")) { // diagnostic: what was built
+        unsigned int e[2] = {0, 0};
+        (void)hipMemcpy(e, c->band_off + nkeys, sizeof e, hipMemcpyDeviceToHost);
+        fprintf(stderr, "band lists: %d x %d buckets per cell, %zu lists, %llu entries, %u of them on the list \"everywhere\"\n",
+                built_g, built_g, nkeys, total64, e[1] - e[0]);
     }
     return RT_OK;
 }

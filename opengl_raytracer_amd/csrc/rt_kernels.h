@@ -1993,16 +1993,11 @@ __global__ __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(BLOCK) v
 // records (positions in nrecs) whose band shares a direction with the cell.  One thread per member
 // walks the cells from the coarsest level down, as grid_build_kernel does.  A member whose band is
 // every direction goes on the list "everywhere" (index num_cells); padding and never-accepted
-// members on none.  With G > 1 a cell has G x G lists more, by the origin of the ray (rt_grid.h,
-// "Origin buckets"): list cell * (G^2 + 1) + bucket holds the members whose slab reaches the bucket,
-// list cell * (G^2 + 1) + G^2 the whole cell; the list "everywhere" is index num_cells * (G^2 + 1).
-// FILL as in grid_build_kernel.
+// members on none.  FILL as in grid_build_kernel.
 // ---------------------------------------------------------------------------
 template <bool FILL>
 __global__ __launch_bounds__(BLOCK) void band_build_kernel(const rtg::CellCone *__restrict__ cells, int bits,
                                                            const float4 *__restrict__ nrecs, int num_members,
-                                                           const rtg::BucketFrame *__restrict__ frames, int G,
-                                                           float cx, float cy, float cz,
                                                            unsigned int *__restrict__ count,
                                                            const unsigned int *__restrict__ off,
                                                            int *__restrict__ entries)
@@ -2016,14 +2011,12 @@ __global__ __launch_bounds__(BLOCK) void band_build_kernel(const rtg::CellCone *
     const float4 m1 = nrecs[2 * pos], m2 = nrecs[2 * pos + 1];
     if (__float_as_int(m2.w) < 0 || m1.w == 2.0f) return; // padding / never accepted
     const unsigned int num_cells = 1u << (2 * bits);
-    const unsigned int per_cell = G > 1 ? (unsigned int)(G * G + 1) : 1u;
-    const float ctr[3] = {cx, cy, cz};
-    auto emit = [&](unsigned int key) {
-        const unsigned int k = atomicAdd(&count[key], 1u);
-        if (FILL) entries[off[key] + k] = pos;
+    auto emit = [&](unsigned int cell) {
+        const unsigned int k = atomicAdd(&count[cell], 1u);
+        if (FILL) entries[off[cell] + k] = pos;
     };
     if (m1.x == 0.0f && m1.y == 0.0f && m1.z == 0.0f) { // its band is every direction
-        if (top == 0) emit(num_cells * per_cell);
+        if (top == 0) emit(num_cells);
         return;
     }
     unsigned int (*stack)[BLOCK] = stack_all; // [depth][thread]: (level << 24) | cell
@@ -2037,19 +2030,82 @@ __global__ __launch_bounds__(BLOCK) void band_build_kernel(const rtg::CellCone *
         const rtg::CellCone cc = cells[rtg::level_offset(level) + cell];
         if (!rtg::cell_reaches_upper_hemisphere(cc) || !rtg::cell_meets_band(cc, m1.x, m1.y, m1.z, 1.0f)) continue;
         if (level == bits) {
-            emit(cell * per_cell + per_cell - 1u);
-            if (G > 1) {
-                const rtg::BucketStrip st = rtg::bucket_strip(frames[cell], m2.x, m2.y, m2.z, m1.w, ctr, G);
-                for (int ix = 0; ix < G; ix++) {
-                    int lo, hi;
-                    rtg::bucket_column_range(st, ix, G, &lo, &hi);
-                    for (int iy = lo; iy <= hi; iy++)
-                        if (rtg::bucket_meets_strip(st, ix, iy)) emit(cell * per_cell + (unsigned int)(iy * G + ix));
-                }
-            }
+            emit(cell);
         } else {
             for (unsigned int k = 0; k < 4; k++) stack[sp++][tx] = ((unsigned int)(level + 1) << 24) | (cell * 4 + k);
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Origin buckets of the band sweep's direction cells (rt_grid.h, "Origin buckets"): the list of cell c
+// (cell_off, cell_entries: what band_build_kernel made) is split into G x G lists by the origin of the ray.
+// List c * (G^2 + 1) + bucket holds the members whose slab reaches the bucket, list c * (G^2 + 1) + G^2 the
+// whole cell once more, list num_cells * (G^2 + 1) the members that are in every cell.  One workgroup per
+// cell (the last one copies the list "everywhere"): a thread per member forms the member's strip in the
+// cell's frame and files it under the buckets the strip meets, counted in LDS -- the lists of one cell lie
+// next to each other in memory, so a workgroup's stores fall into a few KB.  FILL = false writes count[]
+// (every list's length, no atomics on global memory), FILL = true the entries, off[] being the scan of
+// count[].  The order of a list's entries is whatever the atomics make it; no result depends on it.
+// grid = num_cells + 1 workgroups.
+// ---------------------------------------------------------------------------
+constexpr int BUCKET_MAX_G = 16;
+template <bool FILL>
+__global__ __launch_bounds__(BLOCK) void band_bucket_kernel(const unsigned int *__restrict__ cell_off,
+                                                            const int *__restrict__ cell_entries, int bits,
+                                                            const float4 *__restrict__ nrecs,
+                                                            const rtg::BucketFrame *__restrict__ frames, int G,
+                                                            float cx, float cy, float cz,
+                                                            unsigned int *__restrict__ count,
+                                                            const unsigned int *__restrict__ off,
+                                                            int *__restrict__ entries)
+{
+    __shared__ unsigned int filed[BUCKET_MAX_G * BUCKET_MAX_G];
+    const unsigned int num_cells = 1u << (2 * bits);
+    const unsigned int cell = blockIdx.x;
+    const unsigned int per_cell = (unsigned int)(G * G + 1);
+    const unsigned int lo = cell_off[cell];
+    const int n = (int)(cell_off[cell + 1] - lo);
+    const int tid = threadIdx.x;
+    if (cell == num_cells) { // the list "everywhere": as it is
+        const unsigned int key = num_cells * per_cell;
+        if (!FILL) {
+            if (tid == 0) count[key] = (unsigned int)n;
+        } else {
+            for (int i = tid; i < n; i += BLOCK) entries[off[key] + i] = cell_entries[lo + i];
+        }
+        return;
+    }
+    const unsigned int key0 = cell * per_cell;
+    if (n == 0) { // (a cell that does not reach the upper hemisphere, or that no band crosses)
+        if (!FILL)
+            for (unsigned int b = tid; b < per_cell; b += BLOCK) count[key0 + b] = 0u;
+        return;
+    }
+    for (int b = tid; b < G * G; b += BLOCK) filed[b] = 0u;
+    __syncthreads();
+    const float ctr[3] = {cx, cy, cz};
+    const rtg::BucketFrame frame = frames[cell];
+    const unsigned int whole = FILL ? off[key0 + per_cell - 1u] : 0u;
+    for (int i = tid; i < n; i += BLOCK) {
+        const int pos = cell_entries[lo + i];
+        if (FILL) entries[whole + i] = pos;
+        const float4 m1 = nrecs[2 * pos], m2 = nrecs[2 * pos + 1];
+        const rtg::BucketStrip st = rtg::bucket_strip(frame, m2.x, m2.y, m2.z, m1.w, ctr, G);
+        for (int ix = 0; ix < G; ix++) {
+            int blo, bhi;
+            rtg::bucket_column_range(st, ix, G, &blo, &bhi);
+            for (int iy = blo; iy <= bhi; iy++)
+                if (rtg::bucket_meets_strip(st, ix, iy)) {
+                    const int b = iy * G + ix;
+                    const unsigned int k = atomicAdd(&filed[b], 1u);
+                    if (FILL) entries[off[key0 + b] + k] = pos;
+                }
+        }
+    }
+    if (!FILL) {
+        __syncthreads();
+        for (unsigned int b = tid; b < per_cell; b += BLOCK) count[key0 + b] = b + 1u == per_cell ? (unsigned int)n : filed[b];
     }
 }
 
