@@ -427,7 +427,11 @@ extern "C" int rt_create(rt_ctx **out, int hip_device, int width, int height)
     } while (0)
     CRCHK(hipSetDevice(hip_device));
     CRCHK(static_stage_address(hip_device, &c->static_stage));
+    // (both streams now, one after the other: streams are dealt onto the process's few hardware queues in the
+    // order they are made, and a side stream made later can land on its main stream's queue -- the two sweeps
+    // of a bounce pass then run in turn after all: 0.5 ms per frame, measured)
     CRCHK(hipStreamCreateWithFlags(&c->stream_own, hipStreamNonBlocking));
+    CRCHK(hipStreamCreateWithFlags(&c->stream_side, hipStreamNonBlocking));
     CRCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     CRCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     c->stream = c->stream_own;
@@ -1324,9 +1328,6 @@ static bool sweeps_side_by_side(const rt_ctx *c) { return !c->sweeps_in_turn; }
 // Opens the kernel-log record of a clustered bounce pass and lets the side stream run from here on.
 static int fork_side_stream(rt_ctx *c, int n_slot, size_t *ks)
 {
-    // (the side stream exists from the first pass that wants it: a context whose sweeps run in turn, one
-    // of several that take frames in turn, say, should not take up a second hardware queue)
-    if (!c->stream_side) HIPCHK(c, hipStreamCreateWithFlags(&c->stream_side, hipStreamNonBlocking));
     if (int r = klog_begin(c, 1, 2, 1, false, n_slot, 0ull, (unsigned long long)c->num_tris, ks)) return r;
     HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->stream_side, c->ev_fork, 0));
