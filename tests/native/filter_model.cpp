@@ -532,6 +532,34 @@ extern "C" void fm_check_band_cells(int n_tris, const float *verts, int n_rays, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// bucket_column_range() against bucket_meets_strip() over every bucket: the band_bucket_kernel loops over
+// the range only, so a bucket that meets the strip outside it would be a member missing from a list.
+// strips: n x 8 doubles (k, a, b, bound, u0, v0, su, sv).
+// stats: [0] buckets that meet their strip [1] of them outside the column's range [2] buckets in ranges
+// ---------------------------------------------------------------------------------------------
+extern "C" void fm_check_bucket_columns(int n, const double *strips, int G, long long *stats)
+{
+    long long meet = 0, bad = 0, ranged = 0;
+    for (int i = 0; i < n; i++) {
+        const double *q = strips + 8 * i;
+        rtg::BucketStrip st;
+        st.k = q[0]; st.a = q[1]; st.b = q[2]; st.bound = q[3]; st.u0 = q[4]; st.v0 = q[5]; st.su = q[6]; st.sv = q[7];
+        for (int ix = 0; ix < G; ix++) {
+            int lo, hi;
+            rtg::bucket_column_range(st, ix, G, &lo, &hi);
+            if (hi >= lo) ranged += hi - lo + 1;
+            if (lo < 0 || hi > G - 1) bad++;
+            for (int iy = 0; iy < G; iy++)
+                if (rtg::bucket_meets_strip(st, ix, iy)) {
+                    meet++;
+                    bad += !(iy >= lo && iy <= hi);
+                }
+        }
+    }
+    stats[0] = meet; stats[1] = bad; stats[2] = ranged;
+}
+
+// ---------------------------------------------------------------------------------------------
 // The cells of a walk by rank (rt_voxel.h: event_rank and friends, what traverse_voxel_long_kernel's 64
 // lanes compute together) against the cells walk_step() finds one after the other, on a grid given by
 // its corner, cell size and cell counts, round after round of 64 steps until the walk leaves the grid:

@@ -779,6 +779,36 @@ def test_band_cell_origin_buckets_hold_every_member_a_ray_is_inside(fm, buckets,
         assert st["listed"] < 0.4 * whole["listed"], (st, whole)
 
 
+@pytest.mark.parametrize("G", [2, 8, 16])
+def test_bucket_column_ranges_hold_every_bucket_that_meets_the_strip(fm, G):
+    """band_bucket_kernel visits, per column of a cell's origin buckets, only the rows bucket_column_range()
+    names: no bucket that meets the member's strip may lie outside (strips steep, flat, along a column,
+    far off the box, with tiny and huge coefficients), and the ranges must not be the whole column either."""
+    rs = np.random.RandomState(211 + G)
+    n = 20000
+    mag = 10.0 ** rs.uniform(-3, 4, (n, 1))
+    ang = rs.uniform(0, 2 * np.pi, (n, 1))
+    a, b = mag * np.cos(ang), mag * np.sin(ang)
+    kind = rs.randint(0, 6, (n, 1))
+    a = np.where(kind == 0, 0.0, a); b = np.where(kind == 1, 0.0, b)          # axis-parallel strips
+    b = np.where(kind == 2, b * 1e-12, b)                                       # along a column, almost
+    u0, v0 = rs.uniform(-3, 1, (2, n, 1)) * 10.0 ** rs.uniform(-1, 2, (2, n, 1))
+    su, sv = 10.0 ** rs.uniform(-3, 1, (2, n, 1))
+    # through a random point of the box (most), or somewhere else
+    pu, pv = u0 + rs.uniform(-0.2, 1.2, (n, 1)) * su * G, v0 + rs.uniform(-0.2, 1.2, (n, 1)) * sv * G
+    k = -(a * pu + b * pv) + np.where(kind == 3, mag * 100.0, 0.0)
+    bound = 1.0 + 10.0 ** rs.uniform(-3, 2, (n, 1)) + (np.abs(a) * su + np.abs(b) * sv) * 0.501
+    strips = np.ascontiguousarray(np.concatenate([k, a, b, bound, u0, v0, su, sv], 1), dtype=np.float64)
+    st = np.zeros(3, dtype=np.int64)
+    fm.fm_check_bucket_columns.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    fm.fm_check_bucket_columns(n, strips.ctypes.data, G, st.ctypes.data)
+    meet, bad, ranged = (int(x) for x in st)
+    assert bad == 0, (meet, bad, ranged)
+    assert meet > n, (meet, ranged)
+    if G >= 8:
+        assert ranged < 0.9 * n * G * G, (meet, ranged)     # the ranges do cut the work (these strips are wide)
+
+
 # -- the cells of a walk by rank (traverse_voxel_long_kernel) against the cells found step by step -----------
 def run_walk_ranks(fm, gmin, cs, n, back, flat, org, dirs):
     org = np.ascontiguousarray(org, dtype=f32)
