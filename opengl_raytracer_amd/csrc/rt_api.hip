@@ -700,8 +700,12 @@ static int build_band_cells(rt_ctx *c)
         const size_t nk = ncells * ((size_t)G * G + 1);
         DevBuf cnt, off, ent;
         unsigned long long total = 0;
-        HIPCHK(c, hipMalloc(&cnt.p, (nk + 2) * sizeof(unsigned int)));
-        HIPCHK(c, hipMalloc(&off.p, (nk + 2) * sizeof(unsigned int)));
+        // (a device short of memory gets fewer buckets, not an error)
+        if (hipMalloc(&cnt.p, (nk + 2) * sizeof(unsigned int)) != hipSuccess ||
+            hipMalloc(&off.p, (nk + 2) * sizeof(unsigned int)) != hipSuccess) {
+            (void)hipGetLastError();
+            continue;
+        }
         HIPCHK(c, hipMemsetAsync((unsigned int *)cnt.p + nk, 0, 2 * sizeof(unsigned int), c->stream));
         hipLaunchKernelGGL((band_bucket_kernel<false>), dim3((unsigned)ncells + 1), dim3(BLOCK), 0, c->stream,
                            (const unsigned int *)off1.p, (const int *)ent1.p, c->grid_bits, (const float4 *)c->nrec_d,
@@ -719,7 +723,10 @@ static int build_band_cells(rt_ctx *c)
         }
         if (!scan((unsigned int *)cnt.p, (unsigned int *)off.p, nk + 2))
             return fail(c, RT_ERR_HIP, "build_band_cells: scanning the buckets' counts failed");
-        HIPCHK(c, hipMalloc(&ent.p, ((size_t)total + 64) * sizeof(int)));
+        if (hipMalloc(&ent.p, ((size_t)total + 64) * sizeof(int)) != hipSuccess) {
+            (void)hipGetLastError();
+            continue;
+        }
         hipLaunchKernelGGL((band_bucket_kernel<true>), dim3((unsigned)ncells + 1), dim3(BLOCK), 0, c->stream,
                            (const unsigned int *)off1.p, (const int *)ent1.p, c->grid_bits, (const float4 *)c->nrec_d,
                            (const rtg::BucketFrame *)c->bucket_frames_d, G, c->center[0], c->center[1], c->center[2],
