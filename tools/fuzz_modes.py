@@ -17,6 +17,10 @@ from opengl_raytracer_amd import scenes
 from common import describe_mismatch, rays_equal_bits
 
 
+# FUZZ_OPTS="band_buckets=2,grid_bits=8": further options of the context (rt_set_option)
+EXTRA_OPTIONS = dict((k, int(v)) for k, v in (kv.split("=") for kv in os.environ.get("FUZZ_OPTS", "").split(",") if kv))
+
+
 def scene(seed):
     rs = np.random.RandomState(seed)
     parts = []
@@ -47,7 +51,7 @@ def run(first, count, log=print, mode=None):
     for seed in range(first, first + count):
         mesh, cam, lights, nl, w, h, passes = scene(seed)
         out = {}
-        with rt.RayTracer(w, h, options={"sort_min_rays": 16384, "cluster_min_tris": 0}) as g:
+        with rt.RayTracer(w, h, options=dict({"sort_min_rays": 16384, "cluster_min_tris": 0}, **EXTRA_OPTIONS)) as g:
             g.set_mesh(mesh); g.set_texture(scenes.noise_texture(64, 64)); g.set_lights(lights, nl); g.set_camera(*cam)
             for m in (mode, rt.RT_TRACE_EXACT):
                 g.set_trace_mode(m)
