@@ -309,6 +309,34 @@ def test_band_lists_shared_by_contexts_with_the_same_mesh(rt, oracle_mod, monkey
     assert reports() == (1, 0)
 
 
+@pytest.mark.parametrize("offset", [(30.0, -20.0, 15.0), (300.0, -200.0, 150.0)], ids=["near", "far"])
+def test_mesh_far_from_the_world_origin(rt, oracle_mod, offset):
+    """A mesh (and its camera and lights) translated away from the world's origin, where the scene's two
+    fixed spheres stay: coordinates are coarser there, the scene's bounding sphere is mostly empty, the
+    bands are wide and the band lists' origin buckets tile a box far from the centre they are measured
+    from.  Three passes against the oracle."""
+    from opengl_raytracer_amd import scenes
+    w, h = 256, 160
+    off = np.asarray(offset, dtype=np.float64)
+    mesh = scenes.concat_meshes(scenes.triangle_soup(4000, seed=37, extent=0.9, size=0.09),
+                                scenes.quad_grid(10, 10, origin=(-1.3, -1.1, 1.2), du=(2.6, 0, 0), dv=(0, 2.2, 0.3)))
+    mesh = mesh.copy()
+    mesh["pos"] = (mesh["pos"].astype(np.float64) + off).astype(np.float32)
+    lights = scenes.default_lights()
+    for i in range(2):
+        lights[i]["pos"] = (np.asarray(lights[i]["pos"], dtype=np.float64) + off).astype(np.float32)
+    cam = scenes.look_at_camera(tuple(off + np.array([0.2, 0.3, -2.7])), tuple(off))
+    g, c = rt.RayTracer(w, h, options={"sort_min_rays": 4096}), oracle_mod.Oracle(w, h, threads=16)
+    with g:
+        for o in (g, c):
+            o.set_mesh(mesh)
+            o.set_texture(scenes.noise_texture(32, 32))
+            o.set_lights(lights, 2)
+            o.set_camera(*cam)
+        g.render(3); c.render(3)
+        same("mesh at %r" % (offset,), g, c)
+
+
 # -- a camera moved between raygen and intersect ------------------------------------------------------
 @pytest.mark.parametrize("mode,name", MODES[:2], ids=[m[1] for m in MODES[:2]])
 def test_camera_moved_after_raygen(rt, oracle_mod, mode, name):
