@@ -1258,10 +1258,10 @@ static int next_n_slot(rt_ctx *c)
 template <int K, int FORM, bool ANYHIT>
 static void launch_traverse_k(rt_ctx *c, const TraverseParams &p, dim3 grid)
 {
-    if (c->trace_mode == RT_TRACE_EXACT)
-        hipLaunchKernelGGL((traverse_kernel<K, FORM, ANYHIT, true>), grid, dim3(BLOCK), 0, c->stream, p);
+    if (c->trace_mode == RT_TRACE_EXACT) // the all-pairs loop has one form for every kind of ray
+        hipLaunchKernelGGL((traverse_exact_kernel<K, ANYHIT>), grid, dim3(BLOCK), 0, c->stream, p);
     else
-        hipLaunchKernelGGL((traverse_kernel<K, FORM, ANYHIT, false>), grid, dim3(BLOCK), 0, c->stream, p);
+        hipLaunchKernelGGL((traverse_kernel<K, FORM, ANYHIT>), grid, dim3(BLOCK), 0, c->stream, p);
 }
 
 // One launch of the streaming traversal: the rays of a list (at most n_upper of them) against the

@@ -652,7 +652,7 @@ __global__ __launch_bounds__(BLOCK) void bin_scatter_kernel(const unsigned int *
 //                  sequential loop trace.glsl:135-157 keeps.
 //           true : shadow query -- "is any primitive accepted with 0 < t <= tmax", which is
 //                  all raycol_cs.glsl:50 reads of the shadow trace; sets occ[slot].
-//   EXACT   evaluate the reference arithmetic on every pair (validation mode).
+//   (the all-pairs mode, RT_TRACE_EXACT, has a kernel of its own: traverse_exact_kernel)
 //
 // grid = (ray blocks, triangle sub-ranges): blockIdx.y scans `tiles_per_y` LDS tiles
 // starting at tri_begin.  Filter records stream through LDS in tiles of 256 triangles
@@ -766,17 +766,16 @@ __device__ __forceinline__ float readlane_f(float v, int src)
 
 // The shared-origin form is latency-bound in its run and queue handling: six wavefronts per SIMD
 // (80 VGPRs, a handful of spills) beat the four the register allocator would settle for.
-template <int K, int FORM, bool ANYHIT, bool EXACT>
-__global__ __attribute__((amdgpu_waves_per_eu((FORM == 1 && !EXACT) ? 6 : 1, (FORM == 1 && !EXACT) ? 6 : 8)))
+template <int K, int FORM, bool ANYHIT>
+__global__ __attribute__((amdgpu_waves_per_eu(FORM == 1 ? 6 : 1, FORM == 1 ? 6 : 8)))
 __launch_bounds__(BLOCK) void traverse_kernel(TraverseParams p)
 {
-    // FORM 0: tiles of 256 moment records (16 KiB; edge records, 12 KiB, in the all-pairs mode, which
-    // does not read them).  FORM 1: tiles of 1024 cone records (16 KiB); the edge records are only
-    // touched by the rare second level and stay in global memory.
+    // FORM 0: tiles of 256 moment records (16 KiB).  FORM 1: tiles of 1024 cone records (16 KiB); the
+    // edge records are only touched by the rare second level and stay in global memory.
     __shared__ float4 lds4[FORM == 1 ? CONE_TILE : TILE * 4];
     __shared__ float4 run4[FORM == 1 ? CONE_TILE / RUN : 1];       // FORM 1: the cones of the tile's runs
     __shared__ float4 sup4[FORM == 1 ? CONE_TILE / SUPER_RUN : 1]; // ... and of the level above
-    constexpr int TSZ = (FORM == 1 && !EXACT) ? CONE_TILE : TILE;
+    constexpr int TSZ = FORM == 1 ? CONE_TILE : TILE;
 
     const int tid = threadIdx.x;
     const int n = p.count ? *p.count : p.n;
@@ -789,8 +788,8 @@ __launch_bounds__(BLOCK) void traverse_kernel(TraverseParams p)
 
     int slot[K];
     bool valid[K];
-    // FORM 0: a = the ray's moment about the mesh centre (rt_filter.h, ray_moment; the ray's origin in
-    // the all-pairs mode), b = direction * g, d = direction.
+    // FORM 0: a = the ray's moment about the mesh centre (rt_filter.h, ray_moment), b = direction * g,
+    // d = direction.
     // FORM 1: b = unit direction (times dir_sign); a and d are unused.
     float ax[K], ay[K], az[K], bx[K], by[K], bz[K], dx[K], dy[K], dz[K], g[K], tbest[K];
     int idbest[K];
@@ -821,11 +820,7 @@ __launch_bounds__(BLOCK) void traverse_kernel(TraverseParams p)
             g[k] = rtf::dir_scale(reach, d.x, d.y, d.z);
             dx[k] = d.x; dy[k] = d.y; dz[k] = d.z;
             bx[k] = d.x * g[k]; by[k] = d.y * g[k]; bz[k] = d.z * g[k];
-            if (EXACT) {
-                ax[k] = o.x; ay[k] = o.y; az[k] = o.z;
-            } else {
-                rtf::ray_moment(o.x, o.y, o.z, p.center, bx[k], by[k], bz[k], ax[k], ay[k], az[k]);
-            }
+            rtf::ray_moment(o.x, o.y, o.z, p.center, bx[k], by[k], bz[k], ax[k], ay[k], az[k]);
         } else {
             bx[k] = by[k] = bz[k] = qn;
             g[k] = 1.0f;
@@ -858,12 +853,11 @@ __launch_bounds__(BLOCK) void traverse_kernel(TraverseParams p)
     auto exact_stage_xyz = [&](int tri, v3 X, v3 Y, v3 Z, const bool (&pass)[K]) {
 #pragma unroll
         for (int k = 0; k < K; k++) {
-            if (!EXACT) n_cand += __popcll(__ballot(pass[k]));
+            n_cand += __popcll(__ballot(pass[k]));
             if (pass[k] && !(ANYHIT && occ[k])) {
                 v3 o, d;
                 if (FORM == 0) {
-                    o = EXACT ? rtx::V(ax[k], ay[k], az[k])
-                              : rtx::V(p.job.ox[slot[k]], p.job.oy[slot[k]], p.job.oz[slot[k]]);
+                    o = rtx::V(p.job.ox[slot[k]], p.job.oy[slot[k]], p.job.oz[slot[k]]);
                     d = rtx::V(dx[k], dy[k], dz[k]);
                 } else {
                     o = rtx::V(p.job.ox[slot[k]], p.job.oy[slot[k]], p.job.oz[slot[k]]);
@@ -879,8 +873,8 @@ __launch_bounds__(BLOCK) void traverse_kernel(TraverseParams p)
     };
 
     // FORM 1: queue of (triangle, ray) pairs that passed the cone test, one per wavefront
-    __shared__ unsigned int queue_all[(FORM == 1 && !EXACT) ? (BLOCK / 64) * qcap(K) : 1];
-    unsigned int *queue = queue_all + ((FORM == 1 && !EXACT) ? (tid >> 6) * qcap(K) : 0);
+    __shared__ unsigned int queue_all[FORM == 1 ? (BLOCK / 64) * qcap(K) : 1];
+    unsigned int *queue = queue_all + (FORM == 1 ? (tid >> 6) * qcap(K) : 0);
     int qcount = 0; // wave-uniform
     const int lane = tid & 63;
 
@@ -963,7 +957,7 @@ __launch_bounds__(BLOCK) void traverse_kernel(TraverseParams p)
             __syncthreads();
         }
         const int tile_n = min(TSZ, t_end - tile_base); // triangles of this tile that belong to the range
-        if (FORM == 1 && !EXACT) {
+        if (FORM == 1) {
             const float4 *cs = reinterpret_cast<const float4 *>(p.cones);
 #pragma unroll
             for (int i = 0; i < CONE_TILE / BLOCK; i++) {
@@ -980,19 +974,8 @@ __launch_bounds__(BLOCK) void traverse_kernel(TraverseParams p)
                 sup4[q] = (p.ccones && sc && q * SUPER_RUN < tile_n) ? sc[tile_base / SUPER_RUN + q]
                                                                      : make_float4(0.0f, 0.0f, 0.0f, -2.0f);
             }
-        } else if (!EXACT) {
-            load_tile_moment(lds4, p.mrecs, tile_base, p.num_tris, tid);
         } else {
-            // all-pairs mode: the tile holds the triangles' vertex positions themselves, three float4 per
-            // triangle, copied cooperatively from the reference's 32-byte records and read back with
-            // wave-uniform addresses (LDS broadcast) -- the loop of trace.glsl:135-157 as written
-            const float4 *src = reinterpret_cast<const float4 *>(p.verts);
-#pragma unroll
-            for (int i = 0; i < (TILE * 3) / BLOCK; i++) {
-                const int e = i * BLOCK + tid; // vertex of the tile
-                const int vtx = 3 * tile_base + e;
-                lds4[e] = (vtx < 3 * p.num_tris) ? src[2 * (size_t)vtx] : make_float4(qn, qn, qn, qn);
-            }
+            load_tile_moment(lds4, p.mrecs, tile_base, p.num_tris, tid);
         }
         __syncthreads();
         tris_done += tile_n;
@@ -1002,17 +985,7 @@ __launch_bounds__(BLOCK) void traverse_kernel(TraverseParams p)
         // a wavefront whose rays are all occluded only keeps the barriers company
         if (ANYHIT && wave_decided) continue;
 
-        if (EXACT) {
-            bool pass[K];
-#pragma unroll
-            for (int k = 0; k < K; k++) pass[k] = valid[k];
-            const int tile_tris = min(tile_n, p.num_tris - tile_base);
-            for (int j = 0; j < tile_tris; j++) {
-                const float4 X = lds4[3 * j], Y = lds4[3 * j + 1], Z = lds4[3 * j + 2];
-                exact_stage_xyz(tile_base + j, rtx::V(X.x, X.y, X.z), rtx::V(Y.x, Y.y, Y.z),
-                                rtx::V(Z.x, Z.y, Z.z), pass);
-            }
-        } else if (FORM == 0) {
+        if (FORM == 0) {
             const float *tile = reinterpret_cast<const float *>(lds4);
 #pragma unroll 2
             for (int j = 0; j < TILE; j++) {
@@ -1136,7 +1109,7 @@ __launch_bounds__(BLOCK) void traverse_kernel(TraverseParams p)
             }
         }
     }
-    if (FORM == 1 && !EXACT) drain(true);
+    if (FORM == 1) drain(true);
 
 #ifdef RT_DBG_TIMING
     if ((tid & 63) == 0 && FORM == 1) {
@@ -1169,6 +1142,173 @@ __launch_bounds__(BLOCK) void traverse_kernel(TraverseParams p)
                 ((unsigned long long)__float_as_uint(tbest[k]) << 32) | (unsigned long long)(unsigned int)idbest[k];
             atomicMin(&p.best[slot[k]], key);
         }
+    }
+}
+
+
+// ---------------------------------------------------------------------------
+// RT_TRACE_EXACT: the loop of "OpenGL Raytracer/trace.glsl":135-157 as written -- every ray against
+// every triangle, no acceleration structure, no filter record.
+//
+// A tile of 256 triangles is staged in LDS as (X, e1 = Y - X, e2 = Z - X): the two edge
+// subtractions of trace.glsl:5-6 depend on the triangle alone, so the thread that copies a triangle
+// does them once for the workgroup (the same bits as doing them per pair).  Every wavefront then reads
+// the tile with wave-uniform addresses (LDS broadcast) and evaluates, for K rays per lane and in the
+// reference's own association and rounding,
+//     q = cross(d, e2);  a = dot(e1, q);  s = o - X;  x = dot(s, q)            (trace.glsl:7-12)
+// i.e. everything the shader computes up to its first two `return false` (|a| < 1e-20; u = (1/a) x
+// outside [0, 1]).  22 multiplies/adds per pair, all of them plain v_mul/v_add/v_sub or their packed
+// forms -- nothing fused.  The shader's divide is NOT executed on every pair: from the exact a and x,
+//     x (x - a)  >  2^-20 a^2 + 2^-100        (four more operations)
+// proves that the shader rejects the pair: with rho = x / a the left side is a^2 rho (rho - 1), so
+// rho > 1 + 2^-22 - 2^-44 or rho < -(2^-22 - 2^-44) even after the three roundings of the test itself
+// (each within 2^-24, underflow within 2^-150), and u = RN(RN(1/a) x) = rho (1 + 2 roundings) is then
+// >= 1 + 2^-23 or <= -2^-23: `u < 0 || u > 1` holds (|a| < 2^64 because a^2 is finite, so 1/a is a
+// normal number; a = 0 or |a| < 1e-20 is rejected by the shader's first test whatever x is).  A NaN or
+// an overflow on either side makes the comparison false.  Pairs the comparison does not settle -- about
+// one in the ratio of a triangle's width to the scene's -- are queued per wavefront in LDS and handled 64
+// at a time, one pair per lane, by the reference's whole function (rtx::ray_vs_triangle: IEEE divide,
+// all four tests); its hits merge by a 64-bit atomicMin on (t bits, index) -- the smallest t and among
+// equal t the lowest index, what the sequential loop keeps -- or set the shadow ray's flag.
+// ---------------------------------------------------------------------------
+__host__ __device__ constexpr int exact_qcap(int K) { return 64 * K + 320; }
+
+template <int K, bool ANYHIT>
+__global__ __launch_bounds__(BLOCK) void traverse_exact_kernel(TraverseParams p)
+{
+    __shared__ float4 tile4[TILE * 3];
+    __shared__ unsigned int queue_all[(BLOCK / 64) * exact_qcap(K)];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int n = p.count ? *p.count : p.n;
+    const int s0 = blockIdx.x * (BLOCK * K);
+    if (s0 >= n) return; // whole workgroup leaves together
+    const int t_begin = p.tri_begin + blockIdx.y * p.tiles_per_y * TILE;
+    const int t_end = min(min(t_begin + p.tiles_per_y * TILE, p.tri_end), p.num_tris);
+    if (t_begin >= t_end) return;
+
+    int slot[K];
+    bool valid[K];
+    float ox[K], oy[K], oz[K], dx[K], dy[K], dz[K];
+    unsigned long long live[K]; // wave-uniform: the lanes whose ray k still takes part
+    const float qn = __int_as_float(0x7fc00000);
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        // a wavefront takes 64 K consecutive list entries: K runs of 64 = K neighbouring pixel tiles
+        const int s = s0 + ((tid >> 6) * K + k) * 64 + lane;
+        valid[k] = s < n;
+        slot[k] = valid[k] ? (p.alist ? p.alist[s] : s) : 0;
+        ox[k] = oy[k] = oz[k] = dx[k] = dy[k] = dz[k] = qn;
+        if (valid[k]) {
+            if (ANYHIT && p.occ[slot[k]] != 0) valid[k] = false; // already decided
+            ox[k] = p.job.ox[slot[k]]; oy[k] = p.job.oy[slot[k]]; oz[k] = p.job.oz[slot[k]];
+            dx[k] = p.job.dx[slot[k]]; dy[k] = p.job.dy[slot[k]]; dz[k] = p.job.dz[slot[k]];
+        }
+        live[k] = __builtin_amdgcn_ballot_w64(valid[k]);
+    }
+
+    unsigned int *queue = queue_all + (tid >> 6) * exact_qcap(K);
+    int qcount = 0; // wave-uniform
+    unsigned long long n_cand = 0;
+    int tris_done = 0;
+
+    // the reference's whole test for queued pairs, one pair per lane
+    auto drain = [&](bool all) {
+        while (qcount >= 64 || (all && qcount > 0)) {
+            const int take = qcount >= 64 ? 64 : qcount;
+            qcount -= take;
+            if (lane < take) {
+                const unsigned int e = queue[qcount + lane];
+                const int s = s0 + (int)(e & 2047u);
+                const int tri = t_begin + (int)(e >> 11);
+                const int sl = p.alist ? p.alist[s] : s;
+                const v3 o = rtx::V(p.job.ox[sl], p.job.oy[sl], p.job.oz[sl]);
+                const v3 d = rtx::V(p.job.dx[sl], p.job.dy[sl], p.job.dz[sl]);
+                const v3 X = vpos(p.verts, 3 * tri), Y = vpos(p.verts, 3 * tri + 1), Z = vpos(p.verts, 3 * tri + 2);
+                float t;
+                if (rtx::ray_vs_triangle(o, d, X, Y, Z, t)) {
+                    if (ANYHIT) {
+                        if (t > 0.0f && t <= p.job.tmax[sl]) p.occ[sl] = 1;
+                    } else if (t > 0.0f) {
+                        const unsigned long long key =
+                            ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)(unsigned int)tri;
+                        atomicMin(&p.best[sl], key);
+                    }
+                }
+            }
+        }
+    };
+
+    for (int tile_base = t_begin; tile_base < t_end; tile_base += TILE) {
+        if (ANYHIT) {
+            // shadow rays decided by a drained batch leave the loop; the workgroup leaves when all have
+            bool undecided = false;
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                if (valid[k] && tile_base != t_begin && p.occ[slot[k]] != 0) valid[k] = false;
+                live[k] = __builtin_amdgcn_ballot_w64(valid[k]);
+                undecided = undecided || valid[k];
+            }
+            if (__syncthreads_and(undecided ? 0 : 1)) break;
+        } else {
+            __syncthreads();
+        }
+        const int tile_tris = min(TILE, t_end - tile_base);
+        {
+            // one triangle per thread: X, e1, e2 (trace.glsl:5-6)
+            float4 X = make_float4(qn, qn, qn, qn), E1 = X, E2 = X;
+            if (tid < tile_tris) {
+                const int tri = tile_base + tid;
+                const v3 x = vpos(p.verts, 3 * tri), y = vpos(p.verts, 3 * tri + 1), z = vpos(p.verts, 3 * tri + 2);
+                const v3 e1 = rtx::sub(y, x), e2 = rtx::sub(z, x);
+                X = make_float4(x.x, x.y, x.z, 0.0f);
+                E1 = make_float4(e1.x, e1.y, e1.z, 0.0f);
+                E2 = make_float4(e2.x, e2.y, e2.z, 0.0f);
+            }
+            tile4[3 * tid] = X; tile4[3 * tid + 1] = E1; tile4[3 * tid + 2] = E2;
+        }
+        __syncthreads();
+        tris_done += tile_tris;
+        bool wave_live = false;
+#pragma unroll
+        for (int k = 0; k < K; k++) wave_live = wave_live || live[k] != 0ull;
+        if (!wave_live) continue; // a wavefront without rays only keeps the barriers company
+
+#pragma unroll 2
+        for (int j = 0; j < tile_tris; j++) {
+            const float4 X = tile4[3 * j], E1 = tile4[3 * j + 1], E2 = tile4[3 * j + 2];
+            const unsigned int trel = (unsigned int)(tile_base + j - t_begin) << 11;
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                const float qx = dy[k] * E2.z - E2.y * dz[k];
+                const float qy = dz[k] * E2.x - E2.z * dx[k];
+                const float qz = dx[k] * E2.y - E2.x * dy[k];
+                const float a = E1.x * qx + E1.y * qy + E1.z * qz;
+                const float sx = ox[k] - X.x, sy = oy[k] - X.y, sz = oz[k] - X.z;
+                const float x = sx * qx + sy * qy + sz * qz;
+                const float z = x * (x - a);
+                const float thr = __builtin_fmaf(a * a, 0x1p-20f, 0x1p-100f);
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(!(z > thr)) & live[k];
+                if (m) {
+                    if ((m >> lane) & 1ull)
+                        queue[qcount + lanes_below(m)] = trel | (unsigned int)(((tid >> 6) * K + k) * 64 + lane);
+                    qcount += __popcll(m);
+                }
+            }
+            if (qcount >= exact_qcap(K) - 64 * K) {
+                n_cand += (unsigned long long)(qcount & ~63);
+                drain(false);
+            }
+        }
+    }
+    n_cand += (unsigned long long)qcount;
+    drain(true);
+
+    if (lane == 0) add_counter(p.counters, ANYHIT ? C_SH_CAND : C_CH_CAND, n_cand);
+    if (tid == 0) {
+        const int mine = min(BLOCK * K, n - s0);
+        add_counter(p.counters, ANYHIT ? C_SH_PAIRS : C_CH_PAIRS, (unsigned long long)mine * (unsigned long long)tris_done);
     }
 }
 
