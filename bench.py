@@ -44,14 +44,20 @@ FLOP_PER_TEST = 52.0          # Moller-Trumbore as the reference writes it (trac
 PEAK_FP32_TFLOPS = 157.3      # MI355X vector FP32 peak: 256 CUs x 64 lanes x 4 FLOP (packed FMA) x 2.4 GHz
 PEAK_HBM_GBS = 8000.0         # MI355X HBM3E
 NOMINAL_CLOCK_HZ = 2.4e9
-# VALU issue peak: a SIMD is 16 lanes wide, so a wave64 instruction holds it for 4 clocks (the counters
-# agree: SQ_ACTIVE_INST_VALU, in quad-cycles, is 1.0 per SQ_INSTS_VALU in these kernels):
-# 256 CUs x 4 SIMDs x 0.25 wave-instructions per clock x 2.4 GHz = 614.4 G/s.  One FLOP per lane per
-# instruction -- all this arithmetic may use, since fusing a multiply into an add changes the bits -- is
-# then 39.3 TFLOP/s, a quarter of the packed-FMA peak.
+# VALU issue rates, measured instruction by instruction (tools/microbench/valu_rates.hip, inline assembly;
+# profiles/r03_valu_rates_microbench.txt): packed FP32 (v_pk_fma/mul/add_f32), v_min3/v_max, v_cmp,
+# v_cndmask and v_readlane issue one wave64 instruction per SIMD every four clocks -- 1 per clock per CU,
+# 256 CUs x 2.4 GHz = 614.4 G/s; plain v_fma/v_mul/v_add_f32 issue at twice that (1.76 per clock per CU
+# measured), v_rcp/v_sqrt at half.  So packed and plain FP32 reach the same FLOP rate, and arithmetic that
+# may not fuse a multiply into an add (the reference's: fusing changes the bits) has half the FMA peak:
+# 78.6 TFLOP/s (60-71 sustained in the microbenchmark, where the clock settles near 2.1 GHz).
+# The issue fraction of a kernel is quoted against the 614.4 G/s of the four-clock instructions; a kernel
+# made of plain FP32 arithmetic alone could read up to 1.76 on that scale (none here comes near).
 PEAK_VALU_GINST = 256 * 4 * 0.25 * NOMINAL_CLOCK_HZ / 1e9
-PEAK_UNFUSED_TFLOPS = PEAK_VALU_GINST * 64 / 1e3
+PEAK_UNFUSED_TFLOPS = PEAK_FP32_TFLOPS / 2.0
 RAY_PLANE_BYTES = 56.0        # raygen writes 14 float planes per ray
+PIXEL_BYTES = 4.0             # color writes one RGBA8 pixel per ray
+VISIBLE_GATHER_BYTES = 96.0 + 4.0  # three 32-byte vertices and a texel for a pixel some light reaches
 METRIC = "Mrays/s (primary+secondary) at 4K vs triangle count; % FP32 VALU peak"
 
 # rocprof names of the traversal kernels, by (stage, form) of the library's kernel log
@@ -61,7 +67,10 @@ KERNEL_NAMES = {
     (1, 2): "rtk::traverse_bandcell_kernel",
     (1, 4): "rtk::traverse_voxel_kernel",
     (1, 5): "rtk::traverse_voxel_long_kernel",
+    (2, 6): "rtk::compact_kernel<1>",
+    (2, 7): "rtk::color_finish_kernel",
 }
+EPILOGUE_KERNELS = (KERNEL_NAMES[(2, 6)], KERNEL_NAMES[(2, 7)])
 SIDE_BY_SIDE = "bounce pass: rtk::traverse_bandcell_kernel beside rtk::traverse_voxel_kernel + rtk::traverse_voxel_long_kernel"
 
 
@@ -186,9 +195,10 @@ def named_launches(log, in_turn):
             name = SIDE_BY_SIDE
         elif (stage, form) in KERNEL_NAMES:
             name = KERNEL_NAMES[(stage, form)]
+        elif int(r["exact"]):
+            name = "rtk::traverse_exact_kernel<%d, %s>" % (int(r["rays_per_lane"]), "false" if stage == 1 else "true")
         else:
-            name = "rtk::traverse_kernel<%d, %d, %s, %s>" % (int(r["rays_per_lane"]), form, "false" if stage == 1 else "true",
-                                                          "true" if int(r["exact"]) else "false")
+            name = "rtk::traverse_kernel<%d, %d, %s>" % (int(r["rays_per_lane"]), form, "false" if stage == 1 else "true")
         out.append((name, r))
     return out
 
@@ -198,7 +208,7 @@ def kernel_rooflines(g, job, wl, workload_name):
     bounce pass one after the other and an event pair around every traversal launch (each launch then has a
     duration of its own), grouped by kernel.  For each: the executed VALU issue fraction --
     wave-instructions per launch (committed PMC summary) / live duration / issue peak -- which cannot
-    exceed 1."""
+    exceed 1.  Second result: the shading epilogue of the color stage against the HBM roof."""
     counters, source = committed_counters(workload_name)
     g.set_option("sweeps_in_turn", 1)
     g.set_option("kernel_timing", 1)
@@ -206,9 +216,11 @@ def kernel_rooflines(g, job, wl, workload_name):
         job.render(wl["passes"])
         g.sync()
         g.kernel_log()
+        g.counters()
         job.render(wl["passes"])
         g.sync()
         log = g.kernel_log()
+        cnt = g.counters()
     finally:
         g.set_option("sweeps_in_turn", 0)
         g.set_option("kernel_timing", 0)
@@ -218,6 +230,27 @@ def kernel_rooflines(g, job, wl, workload_name):
     for name, r in named_launches(log, True):
         a = groups.setdefault(name, dict(ms=0.0, launches=0, pairs=0.0, rays=0.0))
         a["ms"] += float(r["ms"]); a["launches"] += 1; a["pairs"] += float(r["pairs"]); a["rays"] += float(r["rays"])
+    # the shading epilogue (raycol_cs.glsl:18-23, 52-127 around the shadow traversal): every pass reads each
+    # pixel's ray (56 B) and writes its pixel (4 B); a pixel that a light reaches gathers three vertices and a
+    # texel; a ray the stage kills is stored again (56 B).  Two kernels: the pass over all pixels, the shading
+    # of the rays it filed.
+    color = None
+    epi = [groups.pop(k) for k in EPILOGUE_KERNELS if k in groups]
+    if len(epi) == 2 and epi[0]["ms"] > 0:
+        passes = epi[0]["launches"]
+        ms = epi[0]["ms"] + epi[1]["ms"]
+        alg = ((RAY_PLANE_BYTES + PIXEL_BYTES) * g.num_rays * passes + VISIBLE_GATHER_BYTES * cnt["lit_pixels"] +
+               RAY_PLANE_BYTES * cnt["killed_rays"])
+        pmc = [counters.get(k, {}).get("hbm_bytes_per_launch") for k in EPILOGUE_KERNELS]
+        color = {"bound": "hbm", "kernel": " + ".join(EPILOGUE_KERNELS), "achieved": alg / (ms * 1e-3) / 1e9,
+                 "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": alg / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                 "traffic": (pmc[0] + pmc[1]) if all(pmc) else None, "traffic_unit": "bytes of HBM per pass (both kernels)",
+                 "bytes_per_pass": alg / passes, "passes": passes, "avg_pass_ms": ms / passes,
+                 "avg_launch_ms": {EPILOGUE_KERNELS[0]: epi[0]["ms"] / passes, EPILOGUE_KERNELS[1]: epi[1]["ms"] / passes},
+                 "lit_pixels_per_frame": cnt["lit_pixels"], "killed_rays_per_frame": cnt["killed_rays"],
+                 "note": "algorithmic bytes: (56 B ray read + 4 B pixel written) x pixels x passes + 100 B of vertex and "
+                         "texel gathers per pixel a light reaches + 56 B per ray the stage kills; the shadow traversal "
+                         "between the two kernels is VALU work and is not in this figure"}
     out = []
     for name, a in sorted(groups.items(), key=lambda kv: -kv[1]["ms"]):
         avg_ms = a["ms"] / a["launches"]
@@ -238,20 +271,24 @@ def kernel_rooflines(g, job, wl, workload_name):
                 # another build of this kernel -- no fraction rather than a wrong one
                 entry.update(counters_source=source, counters_stale=True)
         out.append(entry)
-    return out
+    return out, color
 
 
 def exact_mode_roofline(g, job, wl):
-    """The reference's loop as written, measured in EXECUTED FLOPs: the all-pairs mode (52 FLOP on every
-    (ray, triangle) pair, vertices streamed through LDS tiles) on every 32nd row tile of the frame, two
-    passes; its closest-hit launches against the FP32 vector peak."""
+    """The reference's loop as written (trace.glsl:135-157): the all-pairs mode -- every ray against every
+    triangle, triangles staged in LDS tiles, no acceleration structure -- on every 32nd row tile of the frame,
+    two passes; its closest-hit launches against the FP32 vector peak.  `achieved` prices every pair at the 52
+    FLOP of the shader's test, as the survey's roofline does; the kernel executes 26 per pair (the shader's
+    first 22 and a four-operation test that proves the shader's own early return) and the whole 52 only on the
+    pairs that test leaves open, so `executed` is given beside it."""
     g.set_trace_mode(1)
     g.set_option("kernel_timing", 1)
     try:
         g.set_row_tiles(8, 0, 32)
-        g.render(1); g.sync(); g.kernel_log()
+        g.render(1); g.sync(); g.kernel_log(); g.counters()
         g.render(2); g.sync()
         log = g.kernel_log()
+        cnt = g.counters()
     finally:
         g.set_trace_mode(2)
         g.set_option("kernel_timing", 0)
@@ -265,9 +302,14 @@ def exact_mode_roofline(g, job, wl):
         ms = sum(float(r["ms"]) for r in sel)
         pairs = sum(float(r["pairs"]) for r in sel)
         tf = pairs * FLOP_PER_TEST / (ms * 1e-3) / 1e12
-        out.append({"bound": "valu", "kernel": "rtk::traverse_kernel<%d, %d, false, true> (%s)" % (int(sel[0]["rays_per_lane"]), form, label),
-                    "trace_mode": "exact", "achieved": tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s (executed: 52 per pair)",
-                    "frac": tf / PEAK_FP32_TFLOPS, "frac_of_unfused_peak": tf / PEAK_UNFUSED_TFLOPS, "unfused_peak": PEAK_UNFUSED_TFLOPS,
+        # executed: 26 FLOP on every pair, 52 more on the pairs left open (all closest-hit launches of the sample)
+        open_frac = cnt["closest_candidates"] / max(cnt["closest_pairs"], 1)
+        ex = pairs * (26.0 + FLOP_PER_TEST * open_frac) / (ms * 1e-3) / 1e12
+        out.append({"bound": "valu", "kernel": "rtk::traverse_exact_kernel<%d, false> (%s)" % (int(sel[0]["rays_per_lane"]), label),
+                    "trace_mode": "exact", "achieved": tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s (52 FLOP per pair decided)",
+                    "frac": tf / PEAK_FP32_TFLOPS,
+                    "executed": {"tflops": ex, "flop_per_pair": 26.0 + FLOP_PER_TEST * open_frac, "pairs_left_open": open_frac,
+                                 "unfused_peak": PEAK_UNFUSED_TFLOPS, "frac_of_unfused_peak": ex / PEAK_UNFUSED_TFLOPS},
                     "traffic": None,
                     "launches": len(sel), "avg_launch_ms": ms / len(sel), "pairs_per_launch": pairs / len(sel),
                     "sample": "row tiles of 8 rows, every 32nd, of the same frame"})
@@ -286,7 +328,7 @@ def spawn_ranks(args):
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(sys.argv[0])] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     # a rank that fails must not leave the others waiting in a collective for ever
     import threading
@@ -310,7 +352,10 @@ def spawn_ranks(args):
     return failed or max(abs(c) for c in codes)
 
 
-def main():
+def main(stand_in=None):
+    """stand_in: a callable (width, height, threads) -> renderer that takes the GPU's place.  Only the tests
+    of this program's launcher and sharding pass one (tests/bench_stand_in.py); the benchmark itself has no
+    way to render on anything but the HIP library."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -341,8 +386,6 @@ def main():
     ap.add_argument("--rehearse-collectives", action="store_true",
                     help="one rank: open a process group of one rank all the same and run every collective of the "
                          "multi-rank path (the gather of each frame, barrier, all-reduce) through it")
-    ap.add_argument("--renderer", choices=("hip", "oracle"), default="hip",
-                    help="oracle: the CPU restatement stands in for the GPU (tests of this program's launcher only)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -355,7 +398,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    on_gpu = args.renderer == "hip"
+    on_gpu = stand_in is None
     if on_gpu and args.share_gpu:
         local_rank %= max(torch.cuda.device_count(), 1)
     if on_gpu:
@@ -398,8 +441,7 @@ def main():
             if args.kernel_timing:
                 q.set_option("kernel_timing", 1)
     else:
-        from oracle.rt_oracle import Oracle
-        gs = [Oracle(wl["width"], wl["height"], threads=max(1, (os.cpu_count() or 2) // max(world, 1)))]
+        gs = [stand_in(wl["width"], wl["height"], max(1, (os.cpu_count() or 2) // max(world, 1)))]
     for q in gs:
         setup_scene(q, wl)
     g = gs[0]
@@ -475,15 +517,31 @@ def main():
         cnt = dict(closest_rays=n_px, shadow_rays=0, closest_pairs=0, shadow_pairs=0, closest_candidates=0,
                    shadow_candidates=0, closest_slow_steps=0, shadow_slow_steps=0)
         log, stage_ms = [], [0.0, 0.0, 0.0]
+    # with ranks to gather from: a few more steps, one at a time, that split a step into the rank's own
+    # rendering and the collective (the slowest rank's share is the ceiling of the split, the rest its cost)
+    share_ms, gather_ms = 0.0, 0.0
+    if collectives:
+        marks = []
+        for _ in range(3):
+            sync_all()
+            m = sharding.StepMarks(shard_dev if on_gpu else "cpu")
+            job.render(wl["passes"], marks=m)
+            marks.append(m)
+        sync_all()
+        share_ms = float(np.mean([m.ms()[0] for m in marks]))
+        gather_ms = float(np.mean([m.ms()[1] for m in marks]))
+        if on_gpu:
+            for q in gs:
+                q.counters(); q.kernel_log(); q.stage_ms()
     tot = torch.tensor([cnt["closest_rays"], cnt["shadow_rays"], cnt["closest_pairs"], cnt["shadow_pairs"],
                         cnt["closest_candidates"], cnt["shadow_candidates"], cnt["closest_slow_steps"],
                         cnt["shadow_slow_steps"]], dtype=torch.float64, device=shard_dev)
-    tmax = torch.tensor([dt], dtype=torch.float64, device=shard_dev)
+    tmax = torch.tensor([dt, share_ms, gather_ms], dtype=torch.float64, device=shard_dev)
     if collectives:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     tot = tot.cpu().numpy()
-    dt = float(tmax.item())
+    dt, share_ms_max, gather_ms_max = (float(v) for v in tmax.cpu().numpy())
 
     if rank == 0:
         steps = max(args.steps, 1)
@@ -525,6 +583,11 @@ def main():
             "roofline": None,
             "kernels_rank0": kernels[:6],
         }
+        if collectives:
+            # one step at a time, after the timed region: the slowest rank's rendering of its share (before the
+            # gather) and the longest gather (on rank 0 it includes waiting for the slowest rank)
+            out["share_ms_max"] = share_ms_max
+            out["gather_ms"] = gather_ms_max
         solo = None
         if on_gpu and world == 1 and in_flight > 1:
             # the kernels are timed on one context with nothing beside it (its sweeps side by side again)
@@ -557,21 +620,27 @@ def main():
             g.sync()
             ms_b2b = g.stage_ms()[0] / launches
             gbs = RAY_PLANE_BYTES * g.num_rays / (ms * 1e-3) / 1e9
+            gbs_b2b = RAY_PLANE_BYTES * g.num_rays / (ms_b2b * 1e-3) / 1e9
             pmc = committed_counters(args.workload)[0].get("rtk::raygen_kernel", {})
-            out["roofline_raygen"] = {"bound": "hbm", "kernel": "rtk::raygen_kernel", "achieved": gbs, "peak": PEAK_HBM_GBS,
-                                      "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": pmc.get("hbm_bytes_per_launch"),
-                                      "avg_launch_ms": ms, "bytes_per_launch": RAY_PLANE_BYTES * g.num_rays,
-                                      "back_to_back": {"launches": launches, "avg_launch_ms": ms_b2b,
-                                                       "achieved": RAY_PLANE_BYTES * g.num_rays / (ms_b2b * 1e-3) / 1e9}}
+            # the fraction is the sustained one; inside a frame the launch is shorter because part of its
+            # write-back is still in the Infinity Cache when the next kernel starts
+            out["roofline_raygen"] = {"bound": "hbm", "kernel": "rtk::raygen_kernel", "achieved": gbs_b2b, "peak": PEAK_HBM_GBS,
+                                      "unit": "GB/s", "frac": gbs_b2b / PEAK_HBM_GBS, "traffic": pmc.get("hbm_bytes_per_launch"),
+                                      "avg_launch_ms": ms_b2b, "launches": launches, "bytes_per_launch": RAY_PLANE_BYTES * g.num_rays,
+                                      "in_a_frame": {"avg_launch_ms": ms, "achieved": gbs, "frac": gbs / PEAK_HBM_GBS}}
         if on_gpu and world == 1 and args.trace_mode == 2 and not args.no_kernel_rooflines:
             job = solo or job
-            per_kernel = kernel_rooflines(g, job, wl, args.workload)
+            per_kernel, color = kernel_rooflines(g, job, wl, args.workload)
+            if color:
+                out["roofline_color"] = color
             if per_kernel:
                 dom = dict(per_kernel[0])
                 dom["note"] = ("the kernel with the most time per frame; FP32 vector ALU work, no MFMA; achieved = executed VALU "
                                "wave-instructions per launch (committed PMC summary) / the launch's duration from the hipEvent "
                                "pair around it on the library's stream, kernels of a bounce pass one after the other; peak = "
-                               "1024 SIMDs x 0.25 wave-instructions per clock (16 lanes per SIMD) x 2.4 GHz")
+                               "256 CUs x 1 wave-instruction per clock x 2.4 GHz, the rate of packed, compare, select and "
+                               "cross-lane instructions (plain v_fma/v_mul/v_add_f32 issue at twice that: "
+                               "profiles/r03_valu_rates_microbench.txt)")
                 out["roofline"] = dom
                 out["roofline_kernels"] = per_kernel
             fr = committed_frame(args.workload)

@@ -171,6 +171,9 @@ int rt_set_trace_mode(rt_ctx *ctx, int mode /* rt_trace_mode */);
  *                           reports its duration; 0 (default): the log's records carry ms = 0.  An event
  *                           between two kernels costs the stream about 5 us of idle time, which a frame
  *                           of some thirty traversal launches should not pay unasked
+ *   RT_OPT_EXACT_RAYS_PER_LANE  rays per lane (2, 4 or 8) of the all-pairs kernel of RT_TRACE_EXACT; 0 (default):
+ *                           8 for launches of 2^18 rays that share an origin (2^21 other rays) or more,
+ *                           4 from 65536, else 2
  * RT_OPT_GRID_BITS, RT_OPT_BAND_LIST_MAX, RT_OPT_BAND_BUCKETS and RT_OPT_VOXEL_RES decide what rt_set_mesh builds: after
  * setting one of them the context has no mesh until the next rt_set_mesh. */
 typedef enum rt_option {
@@ -184,7 +187,8 @@ typedef enum rt_option {
     RT_OPT_FAIL_NEXT_STAGE  = 7,
     RT_OPT_MOVING_ORIGIN_LEVELS = 8,
     RT_OPT_KERNEL_TIMING    = 9,
-    RT_OPT_BAND_BUCKETS     = 10
+    RT_OPT_BAND_BUCKETS     = 10,
+    RT_OPT_EXACT_RAYS_PER_LANE = 11
 } rt_option;
 int rt_set_option(rt_ctx *ctx, int option /* rt_option */, long long value);
 
@@ -244,8 +248,13 @@ int rt_stage_ms(rt_ctx *ctx, float ms[3]);
  *   [4] pairs that passed the filter in closest-hit traversal
  *   [5] pairs that passed the filter in shadow traversal
  *   [6] (wavefront, triangle) steps of closest-hit traversal that left the fast path
- *   [7] the same for shadow traversal */
-int rt_get_counters(rt_ctx *ctx, uint64_t counters[8]);
+ *   [7] the same for shadow traversal
+ *   [8] pixels shaded with at least one visible light: the vertex and texel gathers of
+ *       raycol_cs.glsl:82-110 were made for them
+ *   [9] rays killed by the color stage (raycol_cs.glsl:111-115: the ray is stored again)
+ *   [10], [11] reserved (0) */
+#define RT_NUM_COUNTERS 12
+int rt_get_counters(rt_ctx *ctx, uint64_t counters[RT_NUM_COUNTERS]);
 
 /* One record per traversal-kernel launch made by rt_intersect / rt_color since
  * the last rt_kernel_log / rt_create (at most the 1024 most recent launches).
@@ -257,8 +266,11 @@ int rt_get_counters(rt_ctx *ctx, uint64_t counters[8]);
  *           after the other and form 2 is the band sweep alone, followed by 4 = the walk over
  *           cells, one lane per ray, and 5 = the long walks it handed over, one wavefront per ray
  *           (4 and 5 report 0 pairs), 3 = rays sharing an origin, each against the triangle list
- *           of its direction cell
- *   rays_per_lane : 1, 2 or 4
+ *           of its direction cell; with RT_OPT_KERNEL_TIMING also the two kernels of the shading
+ *           epilogue (stage 2, 0 pairs): 6 = the pass over every pixel that files the rays to shade
+ *           and writes the background, 7 = the shading of the filed rays (raycol_cs.glsl:52-127)
+ *   exact : 1 = launched in the all-pairs mode (RT_TRACE_EXACT)
+ *   rays_per_lane : 1, 2, 4 or 8
  *   rays  : rays the launch traversed
  *   pairs : (ray, triangle) pairs = rays x triangles (x lights for stage 2; an
  *           upper bound there, early exit may stop sooner)

@@ -43,7 +43,7 @@ RT_TRACE_CLUSTERED = 2
 # rt_option (include/rt.h)
 OPTIONS = {"sort_min_rays": 0, "cluster_min_tris": 1, "grid_bits": 2, "sweeps_in_turn": 3, "band_list_max": 4,
            "voxel_res": 5, "walk_budget": 6, "fail_next_stage": 7, "moving_origin_levels": 8,
-           "kernel_timing": 9, "band_buckets": 10}
+           "kernel_timing": 9, "band_buckets": 10, "exact_rays_per_lane": 11}
 
 # every symbol include/rt.h declares: name -> (restype, argtypes)
 _P = C.c_void_p

@@ -148,7 +148,7 @@ int RunRaytracer(int windowWidth, int windowHeight, int threadGroupSize, int ren
                                  numVertices / 3, time[0], time[1], time[2], err))
                 std::fprintf(stderr, "%s\n", err.c_str());
         }
-        uint64_t counters[8];
+        uint64_t counters[RT_NUM_COUNTERS];
         RT_CHECK(rt_get_counters(rt, counters));
         const double total = ms[0] + ms[1] + ms[2];
         const double rays = static_cast<double>(windowWidth) * windowHeight * gRenderPasses;

@@ -237,6 +237,7 @@ struct rt_ctx {
     bool fail_next_stage = false;    // RT_OPT_FAIL_NEXT_STAGE
     int moving_origin_levels = 1;    // RT_OPT_MOVING_ORIGIN_LEVELS
     bool sweeps_in_turn = false;     // the two sweeps of a clustered bounce pass one after the other
+    int exact_rays_per_lane = 0;     // all-pairs kernel: 2, 4 or 8 rays per lane, 0 = from the launch's size
     unsigned long long band_list_max = 0xffffff00ull; // longer band lists are not built (32-bit positions)
     // 64-bit totals of the list builders
     unsigned long long *sum_d = nullptr;
@@ -495,8 +496,8 @@ extern "C" int rt_create(rt_ctx **out, int hip_device, int width, int height)
     c->fb = c->fb_own;
     CRCHK(hipMalloc(&c->depth, c->cap * sizeof(float)));
     CRCHK(hipMemsetAsync(c->depth, 0, c->cap * sizeof(float), c->stream));
-    CRCHK(hipMalloc(&c->counters_d, COUNTER_COPIES * 8 * sizeof(unsigned long long)));
-    CRCHK(hipMemsetAsync(c->counters_d, 0, COUNTER_COPIES * 8 * sizeof(unsigned long long), c->stream));
+    CRCHK(hipMalloc(&c->counters_d, COUNTER_COPIES * COUNTER_STRIDE * sizeof(unsigned long long)));
+    CRCHK(hipMemsetAsync(c->counters_d, 0, COUNTER_COPIES * COUNTER_STRIDE * sizeof(unsigned long long), c->stream));
     for (int i = 0; i < rt_ctx::KLOG; i++) {
         CRCHK(hipEventCreate(&c->klog_ev[i].a));
         CRCHK(hipEventCreate(&c->klog_ev[i].b));
@@ -1063,6 +1064,10 @@ extern "C" int rt_set_option(rt_ctx *c, int option, long long value)
         if (value < 0 || value > 4) break;
         c->moving_origin_levels = (int)value;
         return RT_OK;
+    case RT_OPT_EXACT_RAYS_PER_LANE:
+        if (value != 0 && value != 2 && value != 4 && value != 8) break;
+        c->exact_rays_per_lane = (int)value;
+        return RT_OK;
     case RT_OPT_KERNEL_TIMING:
         if (value != 0 && value != 1) break;
         c->kernel_timing = value != 0;
@@ -1258,8 +1263,8 @@ static int next_n_slot(rt_ctx *c)
 template <int K, int FORM, bool ANYHIT>
 static void launch_traverse_k(rt_ctx *c, const TraverseParams &p, dim3 grid)
 {
-    if (c->trace_mode == RT_TRACE_EXACT) // the all-pairs loop has one form for every kind of ray
-        hipLaunchKernelGGL((traverse_exact_kernel<K, ANYHIT>), grid, dim3(BLOCK), 0, c->stream, p);
+    if (c->trace_mode == RT_TRACE_EXACT) // the all-pairs loop has one form for every kind of ray, and holds rays in pairs
+        hipLaunchKernelGGL((traverse_exact_kernel<(K < 2 ? 2 : K), ANYHIT>), grid, dim3(BLOCK), 0, c->stream, p);
     else
         hipLaunchKernelGGL((traverse_kernel<K, FORM, ANYHIT>), grid, dim3(BLOCK), 0, c->stream, p);
 }
@@ -1269,7 +1274,12 @@ static void launch_traverse_k(rt_ctx *c, const TraverseParams &p, dim3 grid)
 // n_upper rays; those beyond the list's end leave at once.)
 static int launch_traverse(rt_ctx *c, TraverseParams p, int n_upper, int n_slot, int form, bool anyhit, int stage)
 {
-    const int k = pick_rays_per_lane(n_upper);
+    int k = pick_rays_per_lane(n_upper);
+    // (the all-pairs kernel holds rays in pairs; eight per lane amortise each LDS read of a triangle best, when
+    // the list is long enough for it: a list of bounce rays is a fraction of the n_upper it is launched for)
+    if (c->trace_mode == RT_TRACE_EXACT)
+        k = c->exact_rays_per_lane ? c->exact_rays_per_lane
+                                   : (n_upper >= (form == 1 ? 1 << 18 : 1 << 21) ? 8 : (k < 2 ? 2 : k));
     const int ray_blocks = cdiv(n_upper, BLOCK * k);
     const int tiles = cdiv(p.tri_end - p.tri_begin, TILE);
     if (ray_blocks <= 0 || tiles <= 0) return RT_OK;
@@ -1289,7 +1299,10 @@ static int launch_traverse(rt_ctx *c, TraverseParams p, int n_upper, int n_slot,
         else if (form == 1 && !anyhit) launch_traverse_k<KK, 1, false>(c, p, grid); \
         else launch_traverse_k<KK, 1, true>(c, p, grid);                            \
     } while (0)
-    if (k == 4) RT_DISPATCH(4);
+    if (k == 8) {
+        if (anyhit) hipLaunchKernelGGL((traverse_exact_kernel<8, true>), grid, dim3(BLOCK), 0, c->stream, p);
+        else hipLaunchKernelGGL((traverse_exact_kernel<8, false>), grid, dim3(BLOCK), 0, c->stream, p);
+    } else if (k == 4) RT_DISPATCH(4);
     else if (k == 2) RT_DISPATCH(2);
     else RT_DISPATCH(1);
 #undef RT_DISPATCH
@@ -1829,11 +1842,17 @@ extern "C" int rt_color(rt_ctx *c)
                 work.keys = c->sort_keys;
                 work.hist = c->bin_hist_d;
             }
+            // (with RT_OPT_KERNEL_TIMING the two kernels of the shading epilogue are logged too: forms 6 and 7)
+            size_t ks_epi = 0;
+            if (c->kernel_timing)
+                if (int r = klog_begin(c, 2, 6, 1, false, -1, (unsigned long long)c->n_rays, 0ull, &ks_epi)) return r;
             hipLaunchKernelGGL((compact_kernel<1>), dim3(list_blocks(c->n_rays, BLOCK * COMPACT_ITERS)), dim3(BLOCK), 0,
                                c->stream, c->rays, (const int *)c->perm_d, (const int *)nullptr, (const int *)nullptr,
                                c->n_rays, (const int *)nullptr, c->list, c->count_d + 1, c->fb, work,
                                c->chunk_filed_d[1], c->chunk_filed_valid[1] ? 1 : 0);
             HIPCHK(c, hipGetLastError());
+            if (c->kernel_timing)
+                if (int r = klog_end(c, ks_epi)) return r;
             c->chunk_filed_valid[1] = true;
             const int *cnt0 = c->count_d + 1;
             const dim3 g0(list_blocks(n0, BLOCK));
@@ -1912,12 +1931,16 @@ extern "C" int rt_color(rt_ctx *c)
                     HIPCHK(c, hipGetLastError());
                 }
             }
+            if (c->kernel_timing)
+                if (int r = klog_begin(c, 2, 7, 1, false, n_slot0, 0ull, 0ull, &ks_epi)) return r;
             hipLaunchKernelGGL(color_finish_kernel, g0, dim3(BLOCK), 0, c->stream, c->rays, (const int *)c->list, cnt0,
                                c->scratch, c->verts, c->num_vertices, (const uint32_t *)c->tex, c->tex_w, c->tex_h,
                                c->fb, c->count_d, c->hits_follow_pixels ? c->feedback_h : (int *)nullptr, c->job,
                                c->lights[c->num_lights - 1], c->cam, c->counters_d,
                                n_slot0 >= 0 ? c->klog_n_d + n_slot0 : (int *)nullptr);
             HIPCHK(c, hipGetLastError());
+            if (c->kernel_timing)
+                if (int r = klog_end(c, ks_epi)) return r;
             c->count_clean[0] = true;
         }
     }
@@ -2030,17 +2053,19 @@ extern "C" int rt_read_depth(rt_ctx *c, float *out)
     return RT_OK;
 }
 
-extern "C" int rt_get_counters(rt_ctx *c, uint64_t counters[8])
+extern "C" int rt_get_counters(rt_ctx *c, uint64_t counters[RT_NUM_COUNTERS])
 {
     if (!c || !counters) return RT_ERR_ARG;
     if (int r = use_device(c)) return r;
-    std::vector<uint64_t> copies((size_t)COUNTER_COPIES * 8);
+    static_assert(RT_NUM_COUNTERS <= COUNTER_STRIDE, "a copy holds every counter");
+    std::vector<uint64_t> copies((size_t)COUNTER_COPIES * COUNTER_STRIDE);
     HIPCHK(c, hipMemcpyAsync(copies.data(), c->counters_d, copies.size() * sizeof(uint64_t), hipMemcpyDeviceToHost,
                              c->stream));
     HIPCHK(c, hipMemsetAsync(c->counters_d, 0, copies.size() * sizeof(uint64_t), c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (int i = 0; i < 8; i++) counters[i] = 0;
-    for (size_t i = 0; i < copies.size(); i++) counters[i & 7] += copies[i];
+    for (int i = 0; i < RT_NUM_COUNTERS; i++) counters[i] = 0;
+    for (size_t i = 0; i < copies.size(); i++)
+        if ((int)(i % COUNTER_STRIDE) < RT_NUM_COUNTERS) counters[i % COUNTER_STRIDE] += copies[i];
     return RT_OK;
 }
 

@@ -40,15 +40,16 @@ struct Camera {
 };
 
 // counters (see rt_get_counters)
-enum { C_CH_RAYS = 0, C_SH_RAYS, C_CH_PAIRS, C_SH_PAIRS, C_CH_CAND, C_SH_CAND, C_CH_SLOW, C_SH_SLOW };
+enum { C_CH_RAYS = 0, C_SH_RAYS, C_CH_PAIRS, C_SH_PAIRS, C_CH_CAND, C_SH_CAND, C_CH_SLOW, C_SH_SLOW, C_LIT, C_KILLS };
+constexpr int COUNTER_STRIDE = 16; // words per copy: the counters above and room to spare, two 64-byte lines
 
-// The eight counters are kept in COUNTER_COPIES copies, one 64-byte line each, picked by the
+// The counters are kept in COUNTER_COPIES copies, on lines of their own, picked by the
 // workgroup's index: atomics of one launch on one address are served one after the other (about 4 ns
 // each), which a launch of 10^5 wavefronts would otherwise wait for.  rt_get_counters adds the copies.
 constexpr int COUNTER_COPIES = 256;
 __device__ __forceinline__ void add_counter(unsigned long long *c, int which, unsigned long long v)
 {
-    if (v) atomicAdd(&c[((blockIdx.x + blockIdx.y * 7u) % COUNTER_COPIES) * 8 + which], v);
+    if (v) atomicAdd(&c[((blockIdx.x + blockIdx.y * 7u) % COUNTER_COPIES) * COUNTER_STRIDE + which], v);
 }
 
 // ---------------------------------------------------------------------------
@@ -1157,8 +1158,10 @@ __launch_bounds__(BLOCK) void traverse_kernel(TraverseParams p)
 // reference's own association and rounding,
 //     q = cross(d, e2);  a = dot(e1, q);  s = o - X;  x = dot(s, q)            (trace.glsl:7-12)
 // i.e. everything the shader computes up to its first two `return false` (|a| < 1e-20; u = (1/a) x
-// outside [0, 1]).  22 multiplies/adds per pair, all of them plain v_mul/v_add/v_sub or their packed
-// forms -- nothing fused.  The shader's divide is NOT executed on every pair: from the exact a and x,
+// outside [0, 1]).  22 multiplies/adds per pair, nothing fused; a lane holds its rays in pairs, so each is
+// one v_pk_mul_f32 / v_pk_add_f32 for two pairs, the triangle's value broadcast to both halves (packed
+// and plain forms round each component alike).  The shader's divide is NOT executed on every pair: from
+// the exact a and x,
 //     x (x - a)  >  2^-20 a^2 + 2^-100        (four more operations)
 // proves that the shader rejects the pair: with rho = x / a the left side is a^2 rho (rho - 1), so
 // rho > 1 + 2^-22 - 2^-44 or rho < -(2^-22 - 2^-44) even after the three roundings of the test itself
@@ -1173,9 +1176,12 @@ __launch_bounds__(BLOCK) void traverse_kernel(TraverseParams p)
 // ---------------------------------------------------------------------------
 __host__ __device__ constexpr int exact_qcap(int K) { return 64 * K + 320; }
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+
 template <int K, bool ANYHIT>
 __global__ __launch_bounds__(BLOCK) void traverse_exact_kernel(TraverseParams p)
 {
+    static_assert(K % 2 == 0, "rays are held in pairs");
     __shared__ float4 tile4[TILE * 3];
     __shared__ unsigned int queue_all[(BLOCK / 64) * exact_qcap(K)];
 
@@ -1190,7 +1196,7 @@ __global__ __launch_bounds__(BLOCK) void traverse_exact_kernel(TraverseParams p)
 
     int slot[K];
     bool valid[K];
-    float ox[K], oy[K], oz[K], dx[K], dy[K], dz[K];
+    f2 ox[K / 2], oy[K / 2], oz[K / 2], dx[K / 2], dy[K / 2], dz[K / 2]; // ray k = component k % 2 of pair k / 2
     unsigned long long live[K]; // wave-uniform: the lanes whose ray k still takes part
     const float qn = __int_as_float(0x7fc00000);
 #pragma unroll
@@ -1199,12 +1205,14 @@ __global__ __launch_bounds__(BLOCK) void traverse_exact_kernel(TraverseParams p)
         const int s = s0 + ((tid >> 6) * K + k) * 64 + lane;
         valid[k] = s < n;
         slot[k] = valid[k] ? (p.alist ? p.alist[s] : s) : 0;
-        ox[k] = oy[k] = oz[k] = dx[k] = dy[k] = dz[k] = qn;
+        float o0 = qn, o1 = qn, o2 = qn, d0 = qn, d1 = qn, d2 = qn;
         if (valid[k]) {
             if (ANYHIT && p.occ[slot[k]] != 0) valid[k] = false; // already decided
-            ox[k] = p.job.ox[slot[k]]; oy[k] = p.job.oy[slot[k]]; oz[k] = p.job.oz[slot[k]];
-            dx[k] = p.job.dx[slot[k]]; dy[k] = p.job.dy[slot[k]]; dz[k] = p.job.dz[slot[k]];
+            o0 = p.job.ox[slot[k]]; o1 = p.job.oy[slot[k]]; o2 = p.job.oz[slot[k]];
+            d0 = p.job.dx[slot[k]]; d1 = p.job.dy[slot[k]]; d2 = p.job.dz[slot[k]];
         }
+        ox[k / 2][k % 2] = o0; oy[k / 2][k % 2] = o1; oz[k / 2][k % 2] = o2;
+        dx[k / 2][k % 2] = d0; dy[k / 2][k % 2] = d1; dz[k / 2][k % 2] = d2;
         live[k] = __builtin_amdgcn_ballot_w64(valid[k]);
     }
 
@@ -1262,9 +1270,11 @@ __global__ __launch_bounds__(BLOCK) void traverse_exact_kernel(TraverseParams p)
                 const int tri = tile_base + tid;
                 const v3 x = vpos(p.verts, 3 * tri), y = vpos(p.verts, 3 * tri + 1), z = vpos(p.verts, 3 * tri + 2);
                 const v3 e1 = rtx::sub(y, x), e2 = rtx::sub(z, x);
-                X = make_float4(x.x, x.y, x.z, 0.0f);
-                E1 = make_float4(e1.x, e1.y, e1.z, 0.0f);
-                E2 = make_float4(e2.x, e2.y, e2.z, 0.0f);
+                // nine values in 48 bytes, laid out so that two 16-byte reads and one 4-byte read bring every
+                // value into a register that a packed instruction can broadcast from
+                X = make_float4(x.x, x.y, x.z, e1.x);
+                E1 = make_float4(e1.y, e1.z, e2.x, e2.y);
+                E2 = make_float4(e2.z, 0.0f, 0.0f, 0.0f);
             }
             tile4[3 * tid] = X; tile4[3 * tid + 1] = E1; tile4[3 * tid + 2] = E2;
         }
@@ -1277,23 +1287,30 @@ __global__ __launch_bounds__(BLOCK) void traverse_exact_kernel(TraverseParams p)
 
 #pragma unroll 2
         for (int j = 0; j < tile_tris; j++) {
-            const float4 X = tile4[3 * j], E1 = tile4[3 * j + 1], E2 = tile4[3 * j + 2];
+            const float4 T0 = tile4[3 * j], T1 = tile4[3 * j + 1];
+            const float T2 = reinterpret_cast<const float *>(tile4)[12 * j + 8];
+            const v3 X = rtx::V(T0.x, T0.y, T0.z), E1 = rtx::V(T0.w, T1.x, T1.y), E2 = rtx::V(T1.z, T1.w, T2);
             const unsigned int trel = (unsigned int)(tile_base + j - t_begin) << 11;
 #pragma unroll
-            for (int k = 0; k < K; k++) {
-                const float qx = dy[k] * E2.z - E2.y * dz[k];
-                const float qy = dz[k] * E2.x - E2.z * dx[k];
-                const float qz = dx[k] * E2.y - E2.x * dy[k];
-                const float a = E1.x * qx + E1.y * qy + E1.z * qz;
-                const float sx = ox[k] - X.x, sy = oy[k] - X.y, sz = oz[k] - X.z;
-                const float x = sx * qx + sy * qy + sz * qz;
-                const float z = x * (x - a);
-                const float thr = __builtin_fmaf(a * a, 0x1p-20f, 0x1p-100f);
-                const unsigned long long m = __builtin_amdgcn_ballot_w64(!(z > thr)) & live[k];
-                if (m) {
-                    if ((m >> lane) & 1ull)
-                        queue[qcount + lanes_below(m)] = trel | (unsigned int)(((tid >> 6) * K + k) * 64 + lane);
-                    qcount += __popcll(m);
+            for (int g = 0; g < K / 2; g++) {
+                const f2 qx = dy[g] * E2.z - E2.y * dz[g];
+                const f2 qy = dz[g] * E2.x - E2.z * dx[g];
+                const f2 qz = dx[g] * E2.y - E2.x * dy[g];
+                const f2 a = E1.x * qx + E1.y * qy + E1.z * qz;
+                const f2 sx = ox[g] - X.x, sy = oy[g] - X.y, sz = oz[g] - X.z;
+                const f2 x = sx * qx + sy * qy + sz * qz;
+                const f2 z = x * (x - a);
+                const f2 thr = __builtin_elementwise_fma(a * a, f2{0x1p-20f, 0x1p-20f}, f2{0x1p-100f, 0x1p-100f});
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int k = 2 * g + h;
+                    const bool open = !(z[h] > thr[h]); // not settled (or a lane without a ray: NaN)
+                    const unsigned long long m = __builtin_amdgcn_ballot_w64(open) & live[k];
+                    if (m) {
+                        if (open && valid[k])
+                            queue[qcount + lanes_below(m)] = trel | (unsigned int)(((tid >> 6) * K + k) * 64 + lane);
+                        qcount += __popcll(m);
+                    }
                 }
             }
             if (qcount >= exact_qcap(K) - 64 * K) {
@@ -3038,8 +3055,10 @@ __global__ __launch_bounds__(BLOCK) void color_finish_kernel(RaySoA r, const int
     if (n_host && blockIdx.x == 0 && threadIdx.x == 0) *n_host = n;
     // the list counter of the OTHER stage, which no kernel of this stage call reads: zero for its next use
     if (zero_this && blockIdx.x == 0 && threadIdx.x == 0) *zero_this = 0;
+    unsigned int n_lit = 0, n_kill = 0; // per wavefront
     RT_FOR_EACH_SLOT(slot, n) {
     const int i = list0[slot];
+    bool kill = false;
     v3 fin = rtx::V(0.1f, 0.1f, 0.1f);
     float lr = s.lr[slot], lg = s.lg[slot], lb = s.lb[slot];
     bool lit = s.lit[slot] != 0;
@@ -3080,9 +3099,17 @@ __global__ __launch_bounds__(BLOCK) void color_finish_kernel(RaySoA r, const int
         if (id + 3 * 5 - 2 < num_vertices / 3) {
             r.id[i] = -2;
             r.ox[i] = o.x; r.oy[i] = o.y; r.oz[i] = o.z;
+            kill = true;
         }
     }
     fb[i] = rtx::to_unorm8(fin.x) | (rtx::to_unorm8(fin.y) << 8) | (rtx::to_unorm8(fin.z) << 16) | 0xff000000u;
+    n_lit += (unsigned int)__popcll(__builtin_amdgcn_ballot_w64(lit));
+    n_kill += (unsigned int)__popcll(__builtin_amdgcn_ballot_w64(kill));
+    }
+    // (the first lane of a wavefront takes part in every round of the loop that any of its lanes does)
+    if ((threadIdx.x & 63) == 0) {
+        add_counter(counters, C_LIT, n_lit);
+        add_counter(counters, C_KILLS, n_kill);
     }
 }
 

@@ -154,10 +154,11 @@ class RayTracer:
         return [float(x) for x in ms]
 
     def counters(self):
-        c = (C.c_uint64 * 8)()
+        c = (C.c_uint64 * 12)()
         self._chk(self._lib.rt_get_counters(self._ctx, c))
         names = ["closest_rays", "shadow_rays", "closest_pairs", "shadow_pairs",
-                 "closest_candidates", "shadow_candidates", "closest_slow_steps", "shadow_slow_steps"]
+                 "closest_candidates", "shadow_candidates", "closest_slow_steps", "shadow_slow_steps",
+                 "lit_pixels", "killed_rays"]
         return {n: int(c[i]) for i, n in enumerate(names)}
 
     def kernel_log(self):

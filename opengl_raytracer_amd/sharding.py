@@ -18,6 +18,7 @@ of its own, so that the chains of consecutive frames overlap on the GPU.  A fram
 render() is complete once its stream has been waited for (`wait()` does that for all of them).
 """
 import contextlib
+import time
 
 import numpy as np
 import torch
@@ -52,6 +53,32 @@ def _as_list(renderers):
     return list(renderers) if isinstance(renderers, (list, tuple)) else [renderers]
 
 
+class StepMarks:
+    """Three marks on the timeline of one render() call -- before the rank's share is rendered, after it, after
+    the gather -- so that a step can be split into the share's time and the collective's.  On the GPU they are
+    events on the stream the call works on; elsewhere, clock readings."""
+
+    def __init__(self, device):
+        self.cuda = torch.device(device).type == "cuda"
+        self.device = device
+        self.marks = []
+
+    def mark(self):
+        if self.cuda:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.current_stream(self.device))
+            self.marks.append(ev)
+        else:
+            self.marks.append(time.perf_counter())
+
+    def ms(self):
+        """(share_ms, gather_ms) once the work has finished (the caller synchronises first)."""
+        a, b, c = self.marks[:3]
+        if self.cuda:
+            return a.elapsed_time(b), b.elapsed_time(c)
+        return (b - a) * 1e3, (c - b) * 1e3
+
+
 class _Streams:
     """The streams of renderers that run on the GPU with bound framebuffers: a single renderer works on
     the stream that is current when the object is made; several get a stream of their own each (none of
@@ -71,12 +98,13 @@ class _Streams:
     def on(self, i):
         return torch.cuda.stream(self.streams[i]) if self.bound else contextlib.nullcontext()
 
-    def follow(self):
-        """Every renderer's stream waits for the stream that is current (work the caller enqueued there on
-        buffers the renderers are about to overwrite: the gather of the last batch)."""
+    def follow(self, only=None):
+        """Every renderer's stream (or that of renderer `only`) waits for the stream that is current (work the
+        caller enqueued there on buffers the renderers are about to overwrite: the gather of the last batch,
+        the caller's reads of a frame)."""
         if self.bound:
             cur = torch.cuda.current_stream(self.device)
-            for s in self.streams:
+            for s in (self.streams if only is None else [self.streams[only]]):
                 if s != cur:
                     s.wait_stream(cur)
 
@@ -115,10 +143,6 @@ class TileShardedFrame:
         # per renderer: its slab, and on rank 0 the gathered slabs and the assembled frame
         self.locals = [torch.zeros((self.max_rows, self.width, 4), dtype=torch.uint8, device=self.device) for _ in self.rs]
         self.local = self.locals[0]
-        self.streams = _Streams(self.rs, self.device, self.bound)
-        if self.bound:
-            for r, loc in zip(self.rs, self.locals):
-                r.bind_framebuffer(loc.data_ptr())
         if self.rank == 0:
             self.gathered = [[torch.zeros_like(self.local) for _ in range(self.world)] for _ in self.rs]
             # frame row -> position in the concatenated slabs
@@ -128,24 +152,40 @@ class TileShardedFrame:
                 perm[rows_q] = q * self.max_rows + np.arange(rows_q.shape[0])
             self.perm = torch.from_numpy(perm).to(self.device)
             self.frames = [torch.zeros((self.height, self.width, 4), dtype=torch.uint8, device=self.device) for _ in self.rs]
+        # (the streams are made after every tensor they will touch: a stream made here waits for the current
+        # stream, on which the tensors above are being filled)
+        self.streams = _Streams(self.rs, self.device, self.bound)
+        if self.bound:
+            for r, loc in zip(self.rs, self.locals):
+                r.bind_framebuffer(loc.data_ptr())
         self.turn = 0
 
-    def render(self, passes):
+    def render(self, passes, marks=None):
         """Renders this rank's tiles and gathers the frame on rank 0 (returns it there, else None).
         With several renderers the frame is complete once wait() (or a device synchronize) has returned, and
-        its tensor is written again len(renderers) calls later: a caller that reads it on a stream of its own
-        finishes before then."""
+        its tensor is written again len(renderers) calls later; what the caller has enqueued on the current
+        stream by then (its reads of that frame) is waited for before the tensor is overwritten.
+        marks: a StepMarks that receives the three marks of this call."""
         i = self.turn
         self.turn = (self.turn + 1) % len(self.rs)
         r, local = self.rs[i], self.locals[i]
+        self.streams.follow(i)
         with self.streams.on(i):
+            if marks:
+                marks.mark()
             r.render(passes)
             if not self.bound:
                 px = torch.from_numpy(np.ascontiguousarray(r.read_pixels()))
                 local[: px.shape[0]].copy_(px)
+            if marks:
+                marks.mark()
             if not self.gather:
+                if marks:
+                    marks.mark()
                 return local[: self.height]  # one rank owns every tile, rows already in order
             dist.gather(local, self.gathered[i] if self.rank == 0 else None, dst=0)
+            if marks:
+                marks.mark()
             if self.rank != 0:
                 return None
             slabs = torch.cat(self.gathered[i], dim=0)
@@ -176,9 +216,11 @@ class FrameBatch:
         if self.rank == 0:
             self.gathered = [torch.zeros_like(self.local) for _ in range(self.world)]
 
-    def render(self, passes):
+    def render(self, passes, marks=None):
         # this rank's views go to the renderers in turn (a renderer's next view waits for its last one only);
         # none of them starts before the gather of the last batch, which reads the tensor they write, is done
+        if marks:
+            marks.mark()
         self.streams.follow()
         for j, k in enumerate(self.mine):
             i = j % len(self.rs)
@@ -195,9 +237,15 @@ class FrameBatch:
             for r in self.rs:
                 r.bind_framebuffer(0)
             self.streams.wait()
+        if marks:
+            marks.mark()
         if not self.gather:
+            if marks:
+                marks.mark()
             return self.local[: len(self.cameras)]
         dist.gather(self.local, self.gathered if self.rank == 0 else None, dst=0)
+        if marks:
+            marks.mark()
         if self.rank != 0:
             return None
         # view k sits at slab k % world, slot k // world

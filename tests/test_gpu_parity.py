@@ -380,6 +380,11 @@ def test_stage_timers_and_counters(rt):
         # fresh rays share the camera origin (direction cells), shadow rays the light; bounce rays: clustered,
         # one record for the band sweep and the walk over cells running side by side (three records when they
         # run in turn, RT_OPT_SWEEPS_IN_TURN: the band sweep's with the pass's pairs, the walk's two with 0)
+        # with the timing on, the two kernels of each shading epilogue are logged beside them (forms 6, 7: no pairs)
+        epilogue = log[log["form"] >= 6]
+        assert [(int(r["stage"]), int(r["form"])) for r in epilogue] == [(2, 6), (2, 7)] * 2
+        assert (epilogue["ms"] > 0).all() and (epilogue["pairs"] == 0).all() and (epilogue["rays"] > 0).all()
+        log = log[log["form"] < 6]
         forms = [(int(r["stage"]), int(r["form"])) for r in log]
         assert forms in ([(1, 3), (2, 3), (1, 2), (2, 3)], [(1, 3), (2, 3), (1, 2), (1, 4), (1, 5), (2, 3)]), forms
         with_pairs = [0, 1, 2, 3] if len(forms) == 4 else [0, 1, 2, 5]

@@ -98,8 +98,8 @@ def _run_bench(*extra):
     import json
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0",
-                          "--renderer", "oracle", "--backend", "gloo", "--no-cpu-baseline", *extra],
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "bench_stand_in.py"), "--steps", "1", "--warmup", "0",
+                          "--backend", "gloo", "--no-cpu-baseline", *extra],
                          env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -116,5 +116,7 @@ def test_bench_starts_its_own_ranks_and_cuts_one_frame_into_tiles():
     assert two["scaling"] == "strong" and "tiles" in two["config"]["sharding"]
     assert two["config"]["frame_crc32"] == one["config"]["frame_crc32"] is not None
     assert two["config"]["rays_per_step"] == one["config"]["rays_per_step"]
+    # a line of more than one rank says how a step splits into the slowest rank's share and the gather
+    assert two["share_ms_max"] > 0 and two["gather_ms"] >= 0 and "share_ms_max" not in one
     weak = _run_bench("--workload", "sword_800_p2", "--gpus", "2", "--sharding", "batch")
     assert weak["scaling"] == "weak" and weak["config"]["rays_per_step"] == 2 * one["config"]["rays_per_step"]
