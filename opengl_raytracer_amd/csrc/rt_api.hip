@@ -159,7 +159,10 @@ struct rt_ctx {
     void *scan_temp = nullptr;
     size_t scan_temp_bytes = 0;
     rtg::SlotView *slot_views_d = nullptr; // scratch of the list builder, one per slot
-    unsigned long long *build_count_d = nullptr; // [0] pairs the list builder counted, [1] its fault flag
+    unsigned long long *build_count_d = nullptr; // [0] pairs the list builder counted, [1] its fault flag,
+                                                 // [2], [3]: grid_overflow_kernel
+    unsigned int *build_overflow_d = nullptr;    // a bit per slot: the builder had no room for one of its pairs
+    unsigned long long *build_feedback_h = nullptr; // pinned, per origin: [0], [1] of its last build (never waited for)
     unsigned int *build_keys_d = nullptr, *build_keys_out_d = nullptr; // (cell, slot) pairs before / after the sort
     int *build_vals_d = nullptr;
     size_t build_pairs_cap = 0;
@@ -483,6 +486,8 @@ extern "C" int rt_create(rt_ctx **out, int hip_device, int width, int height)
     CRCHK(hipMalloc(&c->count_d, 8 * sizeof(int)));
     CRCHK(hipHostMalloc(&c->count_h, 8 * sizeof(int)));
     CRCHK(hipHostMalloc(&c->feedback_h, 4 * sizeof(int)));
+    CRCHK(hipHostMalloc(&c->build_feedback_h, 2 * (1 + RT_MAX_LIGHTS) * sizeof(unsigned long long)));
+    memset(c->build_feedback_h, 0, 2 * (1 + RT_MAX_LIGHTS) * sizeof(unsigned long long));
     c->feedback_h[0] = -1;
     CRCHK(hipMalloc(&c->sum_d, sizeof(unsigned long long)));
     CRCHK(hipHostMalloc(&c->sum_h, sizeof(unsigned long long)));
@@ -569,6 +574,8 @@ extern "C" void rt_destroy(rt_ctx *c)
     drop_band_lists(c);
     (void)hipFree(c->slot_views_d);
     (void)hipFree(c->build_count_d);
+    (void)hipFree(c->build_overflow_d);
+    if (c->build_feedback_h) (void)hipHostFree(c->build_feedback_h);
     (void)hipFree(c->build_keys_d);
     (void)hipFree(c->build_keys_out_d);
     (void)hipFree(c->build_vals_d);
@@ -803,6 +810,8 @@ extern "C" int rt_set_mesh(rt_ctx *c, const rt_vertex *vertices, int num_vertice
     drop_band_lists(c);
     c->band_cells_pending = false;
     (void)hipFree(c->slot_views_d); c->slot_views_d = nullptr;
+    (void)hipFree(c->build_overflow_d); c->build_overflow_d = nullptr;
+    memset(c->build_feedback_h, 0, 2 * (1 + RT_MAX_LIGHTS) * sizeof(unsigned long long)); // counts of another mesh
     c->num_vertices = num_vertices;
     c->num_tris = num_vertices / 3;
     {
@@ -1485,58 +1494,84 @@ static int build_grid(rt_ctx *c, int which, const rtf::ConeRec *cones, const rtf
                        recs, (const int *)c->slot_d, (const rt_vertex *)c->verts, origin[0], origin[1], origin[2], extent,
                        reach_max, c->slot_views_d);
     HIPCHK(c, hipGetLastError());
-    // every (cell, slot) pair in one launch, in no particular order; the launch counts the pairs it had
-    // no room for too, and runs again with larger arrays when there were any
-    if (!c->build_count_d) HIPCHK(c, hipMalloc(&c->build_count_d, 2 * sizeof(unsigned long long)));
+    // Every (cell, slot) pair in one launch, in no particular order.  The arrays hold build_pairs_cap pairs
+    // and, behind them, one entry per slot for the slots a launch has no room for (they go on the list
+    // "everywhere": grid_overflow_kernel).  The first build of an origin waits for the pair count and sizes
+    // the arrays by it.  A later build of the same origin -- a light or a camera that moves from frame to
+    // frame -- does not wait: it runs in the arrays there are, every kernel after it takes the count from
+    // the device, and the count comes back to the host on its own (pinned memory), where the NEXT build of
+    // the origin reads it and, when the arrays have become tight, waits once and enlarges them.
+    if (!c->build_count_d) HIPCHK(c, hipMalloc(&c->build_count_d, 4 * sizeof(unsigned long long)));
+    if (!c->build_overflow_d) HIPCHK(c, hipMalloc(&c->build_overflow_d, ((size_t)c->num_slots / 32 + 1) * sizeof(unsigned int)));
+    volatile unsigned long long *fb = c->build_feedback_h + 2 * which; // [0] pairs of this origin's last build, [1] fault
+    if (fb[1] != 0) return fail(c, RT_ERR_HIP, "direction cells: the list builder ran out of stack");
+    const size_t seen = (size_t)fb[0];
+    bool wait = !c->grid_entries[which] || !c->build_keys_d || seen == 0 || seen + seen / 8 > c->build_pairs_cap ||
+                c->grid_cap[which] < c->build_pairs_cap + (size_t)c->num_slots ||
+                c->build_pairs_cap + (size_t)c->num_slots >= ((size_t)1 << 31);
+    if (getenv("RT_LIST_REPORT")) // diagnostic: how this build runs, and what the origin's last build counted
+        fprintf(stderr, "rt: direction cells of origin %d: %s; last build counted %zu pairs, room for %zu\n", which,
+                wait ? "waits for the count" : "in flight", seen, c->build_pairs_cap);
     size_t total = 0;
     for (int attempt = 0;; attempt++) {
         if (!c->build_keys_d) {
             if (c->build_pairs_cap < (size_t)c->num_slots * 8 + 4096) c->build_pairs_cap = (size_t)c->num_slots * 8 + 4096;
-            HIPCHK(c, hipMalloc(&c->build_keys_d, c->build_pairs_cap * sizeof(unsigned int)));
-            HIPCHK(c, hipMalloc(&c->build_keys_out_d, c->build_pairs_cap * sizeof(unsigned int)));
-            HIPCHK(c, hipMalloc(&c->build_vals_d, c->build_pairs_cap * sizeof(int)));
+            const size_t room = c->build_pairs_cap + (size_t)c->num_slots;
+            HIPCHK(c, hipMalloc(&c->build_keys_d, room * sizeof(unsigned int)));
+            HIPCHK(c, hipMalloc(&c->build_keys_out_d, room * sizeof(unsigned int)));
+            HIPCHK(c, hipMalloc(&c->build_vals_d, room * sizeof(int)));
         }
-        HIPCHK(c, hipMemsetAsync(c->build_count_d, 0, 2 * sizeof(unsigned long long), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->build_count_d, 0, 4 * sizeof(unsigned long long), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->build_overflow_d, 0, ((size_t)c->num_slots / 32 + 1) * sizeof(unsigned int), c->stream));
         hipLaunchKernelGGL(grid_list_kernel, dim3(cdiv(c->num_slots, GRID_LIST_WAVES * 64)), dim3(GRID_LIST_WAVES * 64), 0,
                            c->stream, (const rtg::CellCone *)c->cell_cones_d, level,
                            (const rtg::SlotView *)c->slot_views_d, c->num_slots, c->build_keys_d, c->build_vals_d,
                            c->build_count_d, (unsigned long long)c->build_pairs_cap,
-                           reinterpret_cast<int *>(c->build_count_d + 1));
+                           reinterpret_cast<int *>(c->build_count_d + 1), c->build_overflow_d);
         HIPCHK(c, hipGetLastError());
-        unsigned long long *res_h = reinterpret_cast<unsigned long long *>(c->count_h + 4);
-        HIPCHK(c, hipMemcpyAsync(res_h, c->build_count_d, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+        hipLaunchKernelGGL(grid_overflow_kernel, dim3(cdiv(c->num_slots, BLOCK)), dim3(BLOCK), 0, c->stream,
+                           (const unsigned int *)c->build_overflow_d, c->num_slots, (unsigned int)ncells, c->build_keys_d,
+                           c->build_vals_d, c->build_count_d, (unsigned long long)c->build_pairs_cap);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync((void *)fb, c->build_count_d, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+        if (!wait) {
+            total = c->build_pairs_cap + (size_t)c->num_slots; // an upper bound: the kernels read the count themselves
+            break;
+        }
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (res_h[1] != 0) return fail(c, RT_ERR_HIP, "direction cells: the list builder ran out of stack");
-        if (res_h[0] > 0xffffff00ull)
+        if (fb[1] != 0) return fail(c, RT_ERR_HIP, "direction cells: the list builder ran out of stack");
+        if (fb[0] > 0xffffff00ull)
             return fail(c, RT_ERR_NOMEM, "direction cells: %llu list entries for one origin exceed the 32-bit list "
-                        "positions; lower RT_OPT_GRID_BITS", res_h[0]);
-        total = (size_t)res_h[0];
-        if (total <= c->build_pairs_cap) break;
-        if (attempt) return fail(c, RT_ERR_HIP, "direction cells: the list builder counted %zu pairs twice over", total);
+                        "positions; lower RT_OPT_GRID_BITS", (unsigned long long)fb[0]);
+        total = (size_t)fb[0];
+        // (room to spare, so that the builds that follow without waiting stay inside the arrays)
+        if (total + total / 4 <= c->build_pairs_cap || (attempt && total <= c->build_pairs_cap)) break;
+        if (attempt > 1) return fail(c, RT_ERR_HIP, "direction cells: the list builder counted %zu pairs twice over", total);
         (void)hipFree(c->build_keys_d); c->build_keys_d = nullptr;
         (void)hipFree(c->build_keys_out_d); c->build_keys_out_d = nullptr;
         (void)hipFree(c->build_vals_d); c->build_vals_d = nullptr;
-        c->build_pairs_cap = total + total / 4 + 1024;
+        c->build_pairs_cap = total + total / 2 + 1024;
     }
-    if (total > c->grid_cap[which] || !c->grid_entries[which]) {
+    if (c->grid_cap[which] < c->build_pairs_cap + (size_t)c->num_slots || !c->grid_entries[which]) {
         (void)hipFree(c->grid_entries[which]);
         c->grid_entries[which] = nullptr;
-        c->grid_cap[which] = total + total / 4 + 1024;
+        c->grid_cap[which] = c->build_pairs_cap + (size_t)c->num_slots;
         HIPCHK(c, hipMalloc(&c->grid_entries[which], c->grid_cap[which] * sizeof(int)));
     }
     // by cell; the list "everywhere" has key num_cells: one bit more than the cells need
     const unsigned int key_bits = 2u * (unsigned int)level + 1u;
-    if (total < ((size_t)1 << 31)) {
+    const int *n_pairs = reinterpret_cast<const int *>(c->build_count_d + 3); // pairs to sort, on the device
+    if (c->build_pairs_cap + (size_t)c->num_slots < ((size_t)1 << 31)) {
         // counting sort: pairs per cell, a scan that leaves the lists' first positions in grid_off
         // (off[cells + 1] = the total), a scatter that files the slots
         if (int r = bin_begin(c)) return r;
-        hipLaunchKernelGGL(bin_count_kernel, dim3(list_blocks((int)total, BLOCK)), dim3(BLOCK), 0, c->stream,
-                           (const unsigned int *)c->build_keys_d, reinterpret_cast<const int *>(c->build_count_d),
-                           c->bin_hist_d);
+        hipLaunchKernelGGL(bin_count_kernel, dim3(list_blocks((long long)total, BLOCK)), dim3(BLOCK), 0, c->stream,
+                           (const unsigned int *)c->build_keys_d, n_pairs, c->bin_hist_d);
         HIPCHK(c, hipGetLastError());
-        return bin_finish(c, c->build_keys_d, reinterpret_cast<const int *>(c->build_count_d), (int)total, ncells + 2,
-                          c->grid_entries[which], c->grid_off[which], c->build_vals_d);
+        return bin_finish(c, c->build_keys_d, n_pairs, (int)total, ncells + 2, c->grid_entries[which], c->grid_off[which],
+                          c->build_vals_d);
     }
+    // (lists of 2^31 entries or more: every such build waits, and `total` is the count)
     {
         size_t bytes = 0;
         HIPCHK(c, rocprim::radix_sort_pairs(nullptr, bytes, c->build_keys_d, c->build_keys_out_d, c->build_vals_d,

@@ -1384,8 +1384,11 @@ constexpr int BUILD_STACK = 3 * (rtg::MAX_BITS - BUILD_TOP_LEVEL) + 8; // entrie
 // nodes from a stack of S adds at most 3 per level below the node on top, under 30 in all, which is
 // the room GRID_LIST_RESERVE keeps free.
 //   A slot for the list "everywhere" is appended once, under cell num_cells.
-//   *cursor counts every pair, stored or not: pairs beyond `cap` are dropped and the host, which
-// reads the total anyway to size the sort, runs the launch again with larger arrays.
+//   *cursor counts every pair, stored or not.  Pairs beyond `cap` are not stored; their slots are marked in
+// overflow[] (a bit per slot) and grid_overflow_kernel then lists each marked slot once under "everywhere",
+// in the num_slots entries kept free behind `cap`: a launch that runs out of room loses speed, not pairs
+// (a slot listed twice is tested twice; closest hits merge by a minimum, shadow rays by an or).  The
+// host learns the count afterwards and gives the next build more room.
 //   Where the data comes from decides the speed (the arithmetic is a tenth of the time): a lane's node is
 // any of the 64 slots at any cell, so 64 lanes reading their own views and cones would touch 64 cache
 // lines with every load instruction, twenty-one instructions a step.  Instead each lane keeps the view
@@ -1403,7 +1406,7 @@ constexpr int GRID_LIST_STAGE_PITCH = 13; // 16-byte pieces per node in the stag
 __global__ __launch_bounds__(GRID_LIST_WAVES * 64) void grid_list_kernel(
     const rtg::CellCone *__restrict__ cells, int bits, const rtg::SlotView *__restrict__ views, int num_slots,
     unsigned int *__restrict__ keys, int *__restrict__ vals, unsigned long long *__restrict__ cursor,
-    unsigned long long cap, int *__restrict__ fault)
+    unsigned long long cap, int *__restrict__ fault, unsigned int *__restrict__ overflow)
 {
     static_assert(sizeof(rtg::CellCone) == 48, "four cones are twelve 16-byte pieces");
     __shared__ unsigned int stack_all[GRID_LIST_WAVES][GRID_LIST_STACK];
@@ -1434,6 +1437,8 @@ __global__ __launch_bounds__(GRID_LIST_WAVES * 64) void grid_list_kernel(
             if (base + (unsigned long long)k < cap) {
                 keys[base + k] = okey[k];
                 vals[base + k] = oval[k];
+            } else {
+                atomicOr(&overflow[oval[k] >> 5], 1u << (oval[k] & 31));
             }
         n_out = 0;
     };
@@ -1571,6 +1576,27 @@ __global__ __launch_bounds__(GRID_LIST_WAVES * 64) void grid_list_kernel(
     }
     wave_sync();
     flush();
+}
+
+// After grid_list_kernel: the slots it had no room for go on the list "everywhere" (key num_cells), once
+// each, behind the `cap` pairs that were stored; counts[3] receives the number of pairs there are to sort.
+// counts: [0] pairs grid_list_kernel counted, [2] marked slots filed so far, [3] the result (all zero but
+// [0] when the launch starts).
+__global__ __launch_bounds__(BLOCK) void grid_overflow_kernel(const unsigned int *__restrict__ overflow, int num_slots,
+                                                              unsigned int num_cells, unsigned int *__restrict__ keys,
+                                                              int *__restrict__ vals, unsigned long long *__restrict__ counts,
+                                                              unsigned long long cap)
+{
+    const unsigned long long total = counts[0];
+    const int slot = blockIdx.x * BLOCK + threadIdx.x;
+    if (slot == 0) atomicAdd(&counts[3], total < cap ? total : cap);
+    if (total <= cap || slot >= num_slots) return;
+    if ((overflow[slot >> 5] >> (slot & 31)) & 1u) {
+        const unsigned long long pos = cap + atomicAdd(&counts[2], 1ull);
+        keys[pos] = num_cells;
+        vals[pos] = slot;
+        atomicAdd(&counts[3], 1ull);
+    }
 }
 
 // Step 3: off[c] = position of the first pair of cell c in the sorted keys (c = 0 .. num_cells + 1:

@@ -609,6 +609,79 @@ def test_frames_in_flight_tiles_on_three_contexts(rt, oracle_mod):
             g.close()
 
 
+def test_lights_move_between_frames_in_flight(rt, oracle_mod):
+    """The reference moves its lights every frame (main.cpp:449).  Three contexts take the frames in turn on
+    streams of their own; before each frame its context gets the lights of that frame, so its lists of the
+    light's direction cells are built again -- without a wait from their second build on.  Every frame equals
+    the oracle's frame with the same lights."""
+    import torch
+    from opengl_raytracer_amd import scenes, sharding
+    sc = small_scene("mixed")
+    w, h, passes = 128, 80, 3
+    dev = torch.device("cuda", 0)
+    gs = [rt.RayTracer(w, h, options={"sort_min_rays": 1024}) for _ in range(3)]
+    c = oracle_mod.Oracle(w, h, threads=8)
+    try:
+        for o in gs + [c]:
+            setup(o, sc, 2)
+        job = sharding.TileShardedFrame(gs, w, h, dev)
+        angles = [0.05 * k for k in range(10)]
+        frames = []
+        for k, a in enumerate(angles):
+            gs[k % 3].set_lights(scenes.default_lights(angle_offset=a), 2)
+            f = job.render(passes)
+            with job.streams.on(k % 3):   # a context's tensor is written again three frames on: keep a copy,
+                frames.append(f.clone())  # made on the context's stream, behind the frame
+        job.wait()
+        torch.cuda.synchronize(dev)
+        for k, a in enumerate(angles):
+            c.set_lights(scenes.default_lights(angle_offset=a), 2)
+            c.render(passes)
+            assert np.array_equal(frames[k].cpu().numpy(), c.read_pixels()), f"frame {k}: pixels differ"
+    finally:
+        for g in gs:
+            g.close()
+
+
+def test_list_build_in_flight_runs_out_of_room(rt, oracle_mod, monkeypatch, capfd):
+    """A light far from the mesh sees every triangle in a cell or two; moved into the mesh it sees each over
+    thousands of cells.  The second build of the light's lists does not wait for its pair count, so it runs in
+    arrays sized for the first: the slots it has no room for go on the list every ray reads, and the frame
+    still equals the oracle's.  The third build finds the count of the second and waits once for larger arrays."""
+    import re
+    from opengl_raytracer_amd import scenes
+    monkeypatch.setenv("RT_LIST_REPORT", "1")
+    w, h, passes = 160, 100, 2
+    mesh = scenes.triangle_soup(3000, seed=41, extent=0.9, size=0.12)
+    cam = scenes.look_at_camera((0.0, 0.0, -60.0), (0, 0, 0))   # far away too: few pairs, little room
+    g, c = rt.RayTracer(w, h), oracle_mod.Oracle(w, h, threads=16)
+
+    def lights_at(pos):
+        l = scenes.default_lights()
+        l[0]["pos"] = pos
+        return l
+
+    with g:
+        for o in (g, c):
+            o.set_mesh(mesh)
+            o.set_texture(scenes.noise_texture(32, 32))
+            o.set_camera(*cam)
+        seen = []
+        for pos in ((0.0, 80.0, -20.0), (0.05, 0.1, -0.02), (0.06, 0.1, -0.02), (0.07, 0.1, -0.02)):
+            for o in (g, c):
+                o.set_lights(lights_at(pos), 1)
+                o.render(passes)
+            same("light at %r" % (pos,), g, c)
+            for m in re.finditer(r"direction cells of origin 1: ([a-z ]+); last build counted (\d+) pairs, room for (\d+)",
+                                 capfd.readouterr().err):
+                seen.append((m.group(1), int(m.group(2)), int(m.group(3))))
+    # first build waits; the second runs in flight; the third finds that the second counted more pairs than
+    # there was room for, waits and enlarges; the fourth is in flight again, with room to spare
+    assert [s[0] for s in seen] == ["waits for the count", "in flight", "waits for the count", "in flight"], seen
+    assert seen[2][1] > seen[2][2], seen
+    assert seen[3][1] <= seen[3][2], seen
+
+
 # -- the benchmark program's collective path, rehearsed on one rank ----------------------------------
 @pytest.mark.parametrize("workload", ["soup64k_4k_p6", "soup256k_64views_1080p"])
 def test_bench_collectives_rehearsed_on_one_rank(workload):
