@@ -162,10 +162,15 @@ def cpu_baseline(wl, seconds_hint=15.0):
                       f"{wl['passes']} passes, oracle with {threads} OpenMP threads, {dt:.1f} s"}
 
 
+def counters_file(workload_name):
+    return os.path.join(ROOT, "profiles", "hbm_traffic_per_launch.json" if workload_name == "soup64k_4k_p6"
+                        else f"hbm_traffic_per_launch_{workload_name}.json")
+
+
 def committed_frame(workload_name):
     """VALU wave-instructions of one whole frame of the workload, from the same committed counter run."""
     try:
-        rec = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic_per_launch.json")))
+        rec = json.load(open(counters_file(workload_name)))
         if rec.get("workload") != workload_name or not rec.get("frame"):
             return None
         return rec["frame"]
@@ -177,7 +182,7 @@ def committed_counters(workload_name):
     """Per-launch hardware counters of the kernels from the committed PMC summary (separate rocprofv3
     runs of this program with --sweeps-in-turn: counters cannot be read from inside the benchmark)."""
     try:
-        rec = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic_per_launch.json")))
+        rec = json.load(open(counters_file(workload_name)))
         if rec.get("workload") != workload_name:
             return {}, None
         return rec["kernels"], "profiles/" + rec["source"]

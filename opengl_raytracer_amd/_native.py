@@ -89,15 +89,52 @@ class RtError(RuntimeError):
         self.code = code
 
 
+def _elf_dynamic(path):
+    """(DT_SONAME or None, [DT_NEEDED names]) of a 64-bit little-endian ELF file, read from its dynamic section."""
+    import struct
+    with open(path, "rb") as f:
+        data = f.read()
+    if data[:6] != b"\x7fELF\x02\x01":
+        raise ValueError(f"{path}: not a 64-bit little-endian ELF file")
+    phoff, = struct.unpack_from("<Q", data, 0x20)
+    phentsize, phnum = struct.unpack_from("<HH", data, 0x36)
+    loads, dyn = [], None
+    for i in range(phnum):
+        ptype, _flags, off, vaddr, _paddr, filesz, _memsz, _align = struct.unpack_from("<IIQQQQQQ", data, phoff + i * phentsize)
+        if ptype == 1:
+            loads.append((vaddr, off, filesz))
+        elif ptype == 2:
+            dyn = (off, filesz)
+    if dyn is None:
+        return None, []
+    entries = [struct.unpack_from("<qQ", data, dyn[0] + k) for k in range(0, dyn[1], 16)]
+    strtab = next((v for t, v in entries if t == 5), None)
+    if strtab is None:
+        return None, []
+    base = next((off + strtab - vaddr for vaddr, off, filesz in loads if vaddr <= strtab < vaddr + filesz), None)
+    if base is None:
+        return None, []
+
+    def name(at):
+        end = data.index(b"\0", base + at)
+        return data[base + at:end].decode()
+
+    soname = next((name(v) for t, v in entries if t == 14), None)
+    return soname, [name(v) for t, v in entries if t == 1]
+
+
 def _share_hip_runtime_with_torch():
     """A process can use the GPU through ONE copy of the HIP runtime only: a second copy finds no
-    device.  PyTorch's ROCm wheels carry their own (torch/lib/libamdhip64.so, soname libamdhip64.so.7,
-    which librt_hip.so's dependency of that name resolves to once it is loaded).  So when torch is
-    installed but not imported yet, its copy is loaded here first -- without importing torch -- and
-    a later `import torch` in the same process finds the runtime it expects."""
+    device.  PyTorch's ROCm wheels carry their own (torch/lib/libamdhip64.so), and a later `import torch`
+    in the same process loads it.  So when torch is installed but not imported yet, its copy is loaded
+    here first -- without importing torch -- provided its soname is the one librt_hip.so asks for
+    (DT_NEEDED), so that the library's dependency resolves to it; then torch finds the runtime it expects.
+    If the sonames differ the two would not share a runtime and this raises, rather than let one of them
+    find "no HIP GPUs" later.  RT_NO_TORCH_HIP_PRELOAD=1 skips all of this (for a process that never
+    imports torch and wants the system's runtime)."""
     import importlib.util
     import sys
-    if "torch" in sys.modules:
+    if "torch" in sys.modules or os.environ.get("RT_NO_TORCH_HIP_PRELOAD") == "1":
         return
     try:
         spec = importlib.util.find_spec("torch")
@@ -106,8 +143,16 @@ def _share_hip_runtime_with_torch():
     if spec is None or not spec.submodule_search_locations:
         return
     path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
-    if os.path.exists(path):
-        C.CDLL(path, mode=C.RTLD_GLOBAL)
+    if not os.path.exists(path):
+        return
+    wanted = [n for n in _elf_dynamic(LIB_PATH)[1] if n.startswith("libamdhip64.so")]
+    soname = _elf_dynamic(path)[0]
+    if wanted and soname not in wanted:
+        raise ImportError(
+            f"{LIB_PATH} was built against {wanted[0]} but the installed torch carries {soname} ({path}): one process "
+            "cannot use both.  Rebuild the library against torch's runtime, or set RT_NO_TORCH_HIP_PRELOAD=1 and "
+            "do not import torch in this process")
+    C.CDLL(path, mode=C.RTLD_GLOBAL)
 
 
 def load():

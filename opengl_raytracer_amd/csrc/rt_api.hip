@@ -925,7 +925,10 @@ extern "C" int rt_set_mesh(rt_ctx *c, const rt_vertex *vertices, int num_vertice
             rtv::VoxelSet vs;
             const double abs_extent = std::sqrt((double)c->center[0] * c->center[0] + (double)c->center[1] * c->center[1] +
                                                 (double)c->center[2] * c->center[2]) + 3.0 * (double)c->radius;
-            rtv::build(vertices, c->num_tris, cs.rho, abs_extent, c->voxel_res, vs);
+            // (a mesh of 2^21 triangles or more never takes the clustered bounce path: rt_intersect sends its
+            // bounce rays through the per-pair filter, so the cells stay empty rather than cost seconds of
+            // box/triangle tests on the host and hundreds of MB that nothing reads)
+            rtv::build(vertices, c->num_tris < (1 << 21) ? c->num_tris : 0, cs.rho, abs_extent, c->voxel_res, vs);
             c->vox = vs.grid;
             HIPCHK(c, hipMalloc(&c->vox_off_d, vs.off.size() * sizeof(unsigned int)));
             HIPCHK(c, hipMalloc(&c->vox_entries_d, (vs.entries.size() + 4) * sizeof(int)));
@@ -1094,12 +1097,18 @@ extern "C" int rt_set_option(rt_ctx *c, int option, long long value)
         if (!(value == 0 || (value >= 4 && value <= rtg::MAX_BITS))) break;
         if (int r = use_device(c)) return r;
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        free_grid_tables(c);
-        drop_band_lists(c);
+        free_grid_tables(c); // (drops the band lists too: they are built for these cells)
         c->grid_bits = (int)value;
         c->have_mesh = false; // every list is built for one resolution
         c->camera_recs_dirty = c->light_recs_dirty = true;
-        return alloc_grid_tables(c);
+        if (int r = alloc_grid_tables(c)) {
+            // without its tables the context falls back to the kernels that need none, rather than keep a
+            // resolution whose tables a later launch would find missing
+            free_grid_tables(c);
+            c->grid_bits = 0;
+            return r;
+        }
+        return RT_OK;
     }
     default:
         return fail(c, RT_ERR_ARG, "rt_set_option: unknown option %d", option);

@@ -12,6 +12,7 @@ Same bar as test_gpu_parity.py: every field of every ray record and every pixel 
 import os
 import subprocess
 import sys
+import time
 
 import numpy as np
 import pytest
@@ -418,11 +419,31 @@ def test_two_ranks_share_one_gpu_tiles(rt, tmp_path):
     process renders."""
     out = str(tmp_path / "frame.npy")
     worker = os.path.join(ROOT, "tests", "mp_tile_worker.py")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + os.getpid() % 2000), WORLD_SIZE="2")
-    procs = [subprocess.Popen([sys.executable, worker, out], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))      # a port that is free now
+    port = sk.getsockname()[1]
+    sk.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2")
+    # (each rank writes to a file of its own: a pipe nobody reads would block a rank that prints a lot)
+    logs = [open(str(tmp_path / f"rank{r}.log"), "w+") for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, worker, out], env=dict(env, RANK=str(r)), stdout=logs[r],
                               stderr=subprocess.STDOUT, text=True) for r in range(2)]
-    logs = [p.communicate(timeout=110)[0] for p in procs]
-    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    try:
+        deadline = time.monotonic() + 110
+        for p in procs:
+            p.wait(timeout=max(1.0, deadline - time.monotonic()))
+    finally:
+        for p in procs:        # a rank that hangs must not keep the GPU after the test has failed
+            if p.poll() is None:
+                p.kill()
+                p.wait()
+    texts = []
+    for f in logs:
+        f.seek(0)
+        texts.append(f.read())
+        f.close()
+    assert all(p.returncode == 0 for p in procs), "\n".join(texts)
     got = np.load(out)
     import mp_tile_worker
     with rt.RayTracer(mp_tile_worker.W, mp_tile_worker.H) as g:

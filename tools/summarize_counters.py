@@ -1,7 +1,8 @@
 """Summarises the rocprofv3 outputs of tools/prof_counters.sh into one text file.
-usage: python tools/summarize_counters.py gpurun_out/prof_<tag> profiles/<name>.txt
+usage: python tools/summarize_counters.py gpurun_out/prof_<tag> profiles/<name>.txt [workload]
 Also writes profiles/hbm_traffic_per_launch.json (kernel -> HBM bytes per launch from FETCH_SIZE and
-WRITE_SIZE with the gfx950 corrections), which bench.py quotes as roofline.traffic."""
+WRITE_SIZE with the gfx950 corrections), which bench.py quotes as roofline.traffic; for a workload other
+than the default one the file is hbm_traffic_per_launch_<workload>.json."""
 import collections
 import csv
 import json
@@ -9,6 +10,7 @@ import os
 import sys
 
 base, out = sys.argv[1], sys.argv[2]
+workload = sys.argv[3] if len(sys.argv) > 3 else "soup64k_4k_p6"
 
 
 def short(n):
@@ -17,7 +19,7 @@ def short(n):
 
 lines = []
 stats = list(csv.DictReader(open(f"{base}/trace/t_kernel_stats.csv")))
-lines.append("== rocprofv3 --kernel-trace --stats (python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --sweeps-in-turn --frames-in-flight 1) ==")
+lines.append(f"== rocprofv3 --kernel-trace --stats (python3 bench.py --workload {workload} --steps 3 --warmup 1 --no-cpu-baseline --sweeps-in-turn --frames-in-flight 1) ==")
 traffic = {}
 lines.append(f"{'kernel':70s} {'calls':>6s} {'avg_us':>12s} {'total_ms':>10s} {'%':>6s}")
 for r in stats[:24]:
@@ -64,7 +66,7 @@ if len(gen) >= 4:
 lines.append("")
 lines.append("== hardware counters, per launch (each --pmc set collected in a run of its own) ==")
 for k, v in agg.items():
-    if not any(s in k for s in ("traverse", "raygen", "finish", "setup", "cluster", "build")):
+    if not any(s in k for s in ("traverse", "raygen", "finish", "setup", "cluster", "build", "compact", "grid_list", "bin_")):
         continue
     n = max(len(calls[(k, f)]) for f in ("pmc_sq/sq", "pmc_fetch/f", "pmc_write/w", "pmc_misc/m"))
     t, _ = dur.get(k, (float("nan"), 0))
@@ -88,9 +90,10 @@ for k, v in agg.items():
                  f"   SQ_WAVE_CYCLES {per.get('SQ_WAVE_CYCLES',0):.4g}  SQ_WAIT_INST_ANY {per.get('SQ_WAIT_INST_ANY',0):.4g}")
     lines.append(f"   SQ_LDS_IDX_ACTIVE {per.get('SQ_LDS_IDX_ACTIVE',0):.4g}  SQ_LDS_BANK_CONFLICT {per.get('SQ_LDS_BANK_CONFLICT',0):.4g}")
 open(out, "w").write("\n".join(lines) + "\n")
-json.dump({"source": os.path.basename(out), "workload": "soup64k_4k_p6",
+json.dump({"source": os.path.basename(out), "workload": workload,
            "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, one run each; FETCH_SIZE x 2 KiB "
                    "(128-byte reads count as 64 on gfx950), WRITE_SIZE x 1 KiB; per launch",
            "frame": frame, "kernels": traffic},
-          open(os.path.join(os.path.dirname(out), "hbm_traffic_per_launch.json"), "w"), indent=1)
+          open(os.path.join(os.path.dirname(out), "hbm_traffic_per_launch.json" if workload == "soup64k_4k_p6"
+                            else f"hbm_traffic_per_launch_{workload}.json"), "w"), indent=1)
 print("\n".join(lines))
