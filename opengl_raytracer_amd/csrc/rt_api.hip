@@ -195,6 +195,11 @@ struct rt_ctx {
     // directions in which a light sees them -- the next shading pass does not sort its shadow rays
     bool hits_follow_pixels = false;
     bool rays_valid = false;
+    // rt_render does not launch raygen when the primary traversal will form the rays itself (traverse_grid_kernel
+    // over fresh rays): until that traversal has run the ray planes are unwritten, and anything else that wants
+    // them writes them first (write_pending_rays) from the camera the frame was begun with
+    bool rays_unwritten = false;
+    Camera raygen_cam{};
     int *chunk_filed_d[2] = {nullptr, nullptr}; // entries each chunk of the compaction filed (rt_intersect's, rt_color's)
     bool chunk_filed_valid[2] = {false, false}; // ... in the last pass over the rays now in the buffer
 
@@ -1019,6 +1024,7 @@ extern "C" int rt_set_row_tiles(rt_ctx *c, int tile_rows, int first_tile, int ti
     c->n_rays = c->local_rows * c->width;
     c->feedback_h[0] = -1; // counts of another share of the frame
     c->rays_valid = false;
+    c->rays_unwritten = false;
     c->chunk_filed_valid[0] = c->chunk_filed_valid[1] = false;
     c->rays_share_camera_origin = false;
     if (c->local_rows) return upload_row_map(c);
@@ -1187,13 +1193,30 @@ static int check_ready(rt_ctx *c, bool need_mesh, bool need_rays, const char *wh
     return use_device(c);
 }
 
-extern "C" int rt_raygen(rt_ctx *c)
+static bool use_grid(const rt_ctx *c);
+
+// the rays rt_render left to the primary traversal, written after all (someone else wants the planes)
+static int write_pending_rays(rt_ctx *c)
 {
-    if (!c) return RT_ERR_ARG;
+    if (!c->rays_unwritten) return RT_OK;
+    c->rays_unwritten = false;
+    if (c->n_rays > 0) {
+        hipLaunchKernelGGL(raygen_kernel, dim3(cdiv(c->n_rays, BLOCK * 4)), dim3(BLOCK), 0, c->stream, c->rays,
+                           c->n_rays, c->width, c->height, c->row_map_d, c->raygen_cam);
+        HIPCHK(c, hipGetLastError());
+    }
+    return RT_OK;
+}
+
+// may_defer: the caller runs rt_intersect next (rt_render), so the launch can be left to the primary traversal
+static int raygen_stage(rt_ctx *c, bool may_defer)
+{
     if (int r = check_ready(c, false, false, "rt_raygen")) return r;
     size_t slot;
     if (int r = stage_begin(c, 0, &slot)) return r;
-    if (c->n_rays > 0) {
+    c->rays_unwritten = may_defer && c->have_mesh && use_grid(c) && c->n_rays > 0;
+    c->raygen_cam = c->cam;
+    if (c->n_rays > 0 && !c->rays_unwritten) {
         hipLaunchKernelGGL(raygen_kernel, dim3(cdiv(c->n_rays, BLOCK * 4)), dim3(BLOCK), 0, c->stream, c->rays,
                            c->n_rays, c->width, c->height, c->row_map_d, c->cam);
         HIPCHK(c, hipGetLastError());
@@ -1203,6 +1226,12 @@ extern "C" int rt_raygen(rt_ctx *c)
     c->chunk_filed_valid[0] = c->chunk_filed_valid[1] = false; // other rays
     c->rays_share_camera_origin = true;
     return RT_OK;
+}
+
+extern "C" int rt_raygen(rt_ctx *c)
+{
+    if (!c) return RT_ERR_ARG;
+    return raygen_stage(c, false);
 }
 
 // ---- launch geometry ---------------------------------------------------------
@@ -1723,6 +1752,11 @@ extern "C" int rt_intersect(rt_ctx *c)
         c->fail_next_stage = false;
         return fail(c, RT_ERR_HIP, "rt_intersect: failure asked for through RT_OPT_FAIL_NEXT_STAGE");
     }
+    // rays rt_render left unwritten are formed by the traversal of fresh rays below, or written now
+    const bool form_rays = c->rays_unwritten && c->rays_share_camera_origin && use_grid(c) && c->n_rays > 0 &&
+                           memcmp(&c->raygen_cam, &c->cam, sizeof(Camera)) == 0;
+    if (!form_rays)
+        if (int r = write_pending_rays(c)) return r;
     if (c->n_rays > 0) {
         const bool shared = c->rays_share_camera_origin;
         const int *list = nullptr, *count = nullptr;
@@ -1808,6 +1842,12 @@ extern "C" int rt_intersect(rt_ctx *c)
         } else if (shared && use_grid(c)) {
             if (fresh_in_kernel) {
                 p.fresh_perm = c->perm_d;
+                p.fresh_raygen = form_rays ? 1 : 0;
+                p.fresh_width = c->width;
+                p.fresh_height = c->height;
+                p.fresh_row_map = c->row_map_d;
+                p.fresh_cam = c->raygen_cam;
+                c->rays_unwritten = false; // (the kernel writes every plane of every ray)
                 p.fresh_rays = c->rays;
                 p.fresh_depth = c->depth;
                 p.fresh_zero = c->count_d + 1;
@@ -1843,6 +1883,7 @@ extern "C" int rt_color(rt_ctx *c)
 {
     if (!c) return RT_ERR_ARG;
     if (int r = check_ready(c, true, true, "rt_color")) return r;
+    if (int r = write_pending_rays(c)) return r;
     StageScope scope{c, 0};
     if (int r = stage_begin(c, 2, &scope.slot)) return r;
     scope.open = true;
@@ -1998,7 +2039,7 @@ extern "C" int rt_render(rt_ctx *c, int passes)
 {
     if (!c) return RT_ERR_ARG;
     if (passes < 1) return fail(c, RT_ERR_ARG, "rt_render: passes=%d must be >= 1", passes);
-    if (int r = rt_raygen(c)) return r;
+    if (int r = raygen_stage(c, true)) return r;
     for (int pss = 0; pss < passes; pss++) {
         c->chain_stage_events = true;
         if (int r = rt_intersect(c)) return r;
@@ -2023,6 +2064,7 @@ extern "C" int rt_read_rays(rt_ctx *c, rt_ray *out)
     if (!c || !out) return RT_ERR_ARG;
     if (int r = use_device(c)) return r;
     if (c->n_rays == 0) return RT_OK;
+    if (int r = write_pending_rays(c)) return r;
     rt_ray *tmp = nullptr;
     HIPCHK(c, hipMalloc(&tmp, (size_t)c->n_rays * sizeof(rt_ray)));
     hipLaunchKernelGGL(soa_to_aos_kernel, dim3(cdiv(c->n_rays, BLOCK)), dim3(BLOCK), 0, c->stream, c->rays, c->n_rays,
@@ -2046,6 +2088,7 @@ extern "C" int rt_read_rays_static(rt_ctx *c, rt_ray *out)
         return fail(c, RT_ERR_ARG, "rt_read_rays_static: %d rays exceed the static staging array (%zu rays of 80 bytes, "
                     "%zu MiB); use rt_read_rays or rt_set_row_tiles", c->n_rays, STATIC_STAGE_MAX_RAYS,
                     STATIC_STAGE_BYTES >> 20);
+    if (int r = write_pending_rays(c)) return r;
     rt_ray *stage = reinterpret_cast<rt_ray *>(c->static_stage);
     hipLaunchKernelGGL(soa_to_aos_kernel, dim3(cdiv(c->n_rays, BLOCK)), dim3(BLOCK), 0, c->stream, c->rays, c->n_rays,
                        stage);
@@ -2059,6 +2102,7 @@ extern "C" int rt_write_rays(rt_ctx *c, const rt_ray *in)
 {
     if (!c || !in) return RT_ERR_ARG;
     if (int r = use_device(c)) return r;
+    c->rays_unwritten = false; // every plane is overwritten
     if (c->n_rays == 0) return RT_OK;
     rt_ray *tmp = nullptr;
     HIPCHK(c, hipMalloc(&tmp, (size_t)c->n_rays * sizeof(rt_ray)));

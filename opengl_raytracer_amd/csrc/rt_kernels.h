@@ -54,14 +54,10 @@ __device__ __forceinline__ void add_counter(unsigned long long *c, int which, un
 
 // ---------------------------------------------------------------------------
 // raygen  ("OpenGL Raytracer/raygen_cs.glsl":1-22)
-// One thread writes four consecutive rays with 16-byte stores: 56 bytes per ray,
-// nothing read but the row map.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void raygen_kernel(RaySoA r, int n_rays, int width, int height,
-                                                       const int *__restrict__ row_map, Camera cam)
+// the direction of the ray through pixel (x, y) of the frame (raygen_cs.glsl:8-17)
+__device__ __forceinline__ v3 raygen_direction(const Camera &cam, int width, int height, int x, int y)
 {
-    const int i0 = (blockIdx.x * BLOCK + threadIdx.x) * 4;
-    if (i0 >= n_rays) return;
     const float hw = (float)width / 2.0f;
     const float hh = (float)height / 2.0f;
     const v3 cpos = rtx::V(cam.pos[0], cam.pos[1], cam.pos[2]);
@@ -69,6 +65,20 @@ __global__ __launch_bounds__(BLOCK) void raygen_kernel(RaySoA r, int n_rays, int
     const v3 cup = rtx::V(cam.up[0], cam.up[1], cam.up[2]);
     const v3 cright = rtx::V(cam.right[0], cam.right[1], cam.right[2]);
     const v3 base = rtx::add(cpos, rtx::muls(cdir, 1.0f));
+    const float fx = ((float)x - hw) / hw;
+    const float fy = ((float)y - hh) / hh;
+    const v3 s = rtx::add(rtx::add(base, rtx::muls(cright, fx)), rtx::muls(cup, fy));
+    return rtx::normalize(rtx::sub(s, cpos));
+}
+
+// One thread writes four consecutive rays with 16-byte stores: 56 bytes per ray,
+// nothing read but the row map.
+__global__ __launch_bounds__(BLOCK) void raygen_kernel(RaySoA r, int n_rays, int width, int height,
+                                                       const int *__restrict__ row_map, Camera cam)
+{
+    const int i0 = (blockIdx.x * BLOCK + threadIdx.x) * 4;
+    if (i0 >= n_rays) return;
+    const v3 cpos = rtx::V(cam.pos[0], cam.pos[1], cam.pos[2]);
 
     float ddx[4], ddy[4], ddz[4];
     int j = i0 / width;
@@ -76,10 +86,7 @@ __global__ __launch_bounds__(BLOCK) void raygen_kernel(RaySoA r, int n_rays, int
     int y = row_map[j];
 #pragma unroll
     for (int e = 0; e < 4; e++) {
-        float fx = ((float)x - hw) / hw;
-        float fy = ((float)y - hh) / hh;
-        v3 s = rtx::add(rtx::add(base, rtx::muls(cright, fx)), rtx::muls(cup, fy));
-        v3 d = rtx::normalize(rtx::sub(s, cpos));
+        const v3 d = raygen_direction(cam, width, height, x, y);
         ddx[e] = d.x; ddy[e] = d.y; ddz[e] = d.z;
         if (++x == width) {
             x = 0;
@@ -319,9 +326,13 @@ __device__ __forceinline__ v3 vpos(const rt_vertex *__restrict__ v, int i)
 // depends only on the winning triangle, so it is formed once here instead of on every improvement inside
 // the loop.
 // ---------------------------------------------------------------------------
+// unwritten: the ray comes straight from raygen and its planes were never written (the primary traversal
+// formed it in registers): what a miss would keep is raygen's normal (0, 0, 0) and colour (1, 0, 0), and
+// every plane is written here.
 __device__ __forceinline__ void intersect_finish_slot(const RaySoA &r, int i, v3 o, v3 d, unsigned long long key,
                                                       const rt_vertex *__restrict__ verts, int num_tris,
-                                                      const float *cam_pos, float *__restrict__ depth)
+                                                      const float *cam_pos, float *__restrict__ depth,
+                                                      bool unwritten = false)
 {
     float tb = __uint_as_float((unsigned int)(key >> 32));
     int id = (int)(unsigned int)(key & 0xffffffffull);
@@ -343,7 +354,7 @@ __device__ __forceinline__ void intersect_finish_slot(const RaySoA &r, int i, v3
     if (kind == 1) {
         const v3 X = vpos(verts, 3 * id), Y = vpos(verts, 3 * id + 1), Z = vpos(verts, 3 * id + 2);
         nrm = rtx::normalize(rtx::cross(rtx::sub(X, Z), rtx::sub(Y, Z)));
-    } else if (kind == 0) {
+    } else if (kind == 0 && !unwritten) {
         nrm = rtx::V(r.nx[i], r.ny[i], r.nz[i]); // a miss keeps the old normal
     }
     v3 ob = rtx::sub(o, rtx::muls(d, 0.001f));
@@ -357,6 +368,9 @@ __device__ __forceinline__ void intersect_finish_slot(const RaySoA &r, int i, v3
     if (kind != 0) {
         r.nx[i] = nrm.x; r.ny[i] = nrm.y; r.nz[i] = nrm.z;
         r.cx[i] = 0.0f; r.cy[i] = 0.0f; r.cz[i] = (kind == 2) ? 1.0f : 0.0f;
+    } else if (unwritten) {
+        r.nx[i] = 0.0f; r.ny[i] = 0.0f; r.nz[i] = 0.0f; // raygen_cs.glsl:18-20
+        r.cx[i] = 1.0f; r.cy[i] = 0.0f; r.cz[i] = 0.0f;
     }
     depth[i] = rtx::distance3(ob, rtx::V(cam_pos[0], cam_pos[1], cam_pos[2]));
 }
@@ -711,7 +725,13 @@ struct TraverseParams {
     // fresh_perm[s], read from the ray planes and set up in registers (rayintersect_cs.glsl:12 and what
     // prepare_shared() forms) -- no set-up kernel, no job planes, no merge of the slots' best hits
     // ... and the kernel finishes them too (intersect_finish_slot: spheres, normal, the new ray, depth)
+    // fresh_raygen: the planes of those rays have not been written -- rt_render skips the raygen launch -- and the
+    // kernel forms ray fresh_perm[s] from its pixel as raygen_kernel would (camera, frame size, row map)
     const int *fresh_perm;
+    int fresh_raygen;
+    int fresh_width, fresh_height;
+    const int *fresh_row_map;
+    Camera fresh_cam;
     RaySoA fresh_rays;
     float *fresh_depth;
     int *fresh_zero; // a counter to zero for the next stage call (intersect_finish_kernel's zero_this)
@@ -1684,8 +1704,15 @@ __global__ __launch_bounds__(BLOCK) void traverse_grid_kernel(TraverseParams p)
     if (valid && fresh) {
         const int i = p.fresh_perm[sl];
         const RaySoA &r = p.fresh_rays;
-        v3 o = rtx::V(r.ox[i], r.oy[i], r.oz[i]);
-        const v3 d = rtx::V(r.dx[i], r.dy[i], r.dz[i]);
+        v3 o, d;
+        if (p.fresh_raygen) {
+            const int j = i / p.fresh_width;
+            o = rtx::V(p.fresh_cam.pos[0], p.fresh_cam.pos[1], p.fresh_cam.pos[2]);
+            d = raygen_direction(p.fresh_cam, p.fresh_width, p.fresh_height, i - j * p.fresh_width, p.fresh_row_map[j]);
+        } else {
+            o = rtx::V(r.ox[i], r.oy[i], r.oz[i]);
+            d = rtx::V(r.dx[i], r.dy[i], r.dz[i]);
+        }
         o = rtx::add(o, rtx::muls(d, 0.001f)); // r.origin = r.origin + r.dir * 0.001
         float bx, by, bz;
         shared_direction(o, d, p.origin, p.center, p.radius, p.reach_max, p.dir_sign, bx, by, bz, g);
@@ -1826,7 +1853,7 @@ __global__ __launch_bounds__(BLOCK) void traverse_grid_kernel(TraverseParams p)
             // the slot's only wavefront: the hit is final, and the ray is finished here
             const float4 ro = ray_o[lane], rd = ray_d[lane];
             intersect_finish_slot(p.fresh_rays, p.fresh_perm[sl], rtx::V(ro.x, ro.y, ro.z), rtx::V(rd.x, rd.y, rd.z), key,
-                                  p.verts, p.num_tris, p.origin, p.fresh_depth);
+                                  p.verts, p.num_tris, p.origin, p.fresh_depth, p.fresh_raygen != 0);
         } else if (key != BEST_NONE) {
             atomicMin(&p.best[sl], key);
         }
