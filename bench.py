@@ -281,7 +281,7 @@ def kernel_rooflines(g, job, wl, workload_name):
 
 def exact_mode_roofline(g, job, wl):
     """The reference's loop as written (trace.glsl:135-157): the all-pairs mode -- every ray against every
-    triangle, triangles staged in LDS tiles, no acceleration structure -- on every 32nd row tile of the frame,
+    triangle, triangles staged in LDS tiles, no acceleration structure -- on every 8th row tile of the frame,
     two passes; its closest-hit launches against the FP32 vector peak.  `achieved` prices every pair at the 52
     FLOP of the shader's test, as the survey's roofline does; the kernel executes 26 per pair (the shader's
     first 22 and a four-operation test that proves the shader's own early return) and the whole 52 only on the
@@ -289,7 +289,7 @@ def exact_mode_roofline(g, job, wl):
     g.set_trace_mode(1)
     g.set_option("kernel_timing", 1)
     try:
-        g.set_row_tiles(8, 0, 32)
+        g.set_row_tiles(8, 0, 8)
         g.render(1); g.sync(); g.kernel_log(); g.counters()
         g.render(2); g.sync()
         log = g.kernel_log()
@@ -317,7 +317,7 @@ def exact_mode_roofline(g, job, wl):
                                  "unfused_peak": PEAK_UNFUSED_TFLOPS, "frac_of_unfused_peak": ex / PEAK_UNFUSED_TFLOPS},
                     "traffic": None,
                     "launches": len(sel), "avg_launch_ms": ms / len(sel), "pairs_per_launch": pairs / len(sel),
-                    "sample": "row tiles of 8 rows, every 32nd, of the same frame"})
+                    "sample": "row tiles of 8 rows, every 8th, of the same frame"})
     return out
 
 

@@ -172,8 +172,7 @@ int rt_set_trace_mode(rt_ctx *ctx, int mode /* rt_trace_mode */);
  *                           between two kernels costs the stream about 5 us of idle time, which a frame
  *                           of some thirty traversal launches should not pay unasked
  *   RT_OPT_EXACT_RAYS_PER_LANE  rays per lane (2, 4 or 8) of the all-pairs kernel of RT_TRACE_EXACT; 0 (default):
- *                           8 for launches of 2^18 rays that share an origin (2^21 other rays) or more,
- *                           4 from 65536, else 2
+ *                           8 for launches of 2^18 rays or more, 4 from 65536, else 2
  * RT_OPT_GRID_BITS, RT_OPT_BAND_LIST_MAX, RT_OPT_BAND_BUCKETS and RT_OPT_VOXEL_RES decide what rt_set_mesh builds: after
  * setting one of them the context has no mesh until the next rt_set_mesh. */
 typedef enum rt_option {

@@ -1322,22 +1322,22 @@ static void launch_traverse_k(rt_ctx *c, const TraverseParams &p, dim3 grid)
 static int launch_traverse(rt_ctx *c, TraverseParams p, int n_upper, int n_slot, int form, bool anyhit, int stage)
 {
     int k = pick_rays_per_lane(n_upper);
-    // (the all-pairs kernel holds rays in pairs; eight per lane amortise each LDS read of a triangle best, when
-    // the list is long enough for it: a list of bounce rays is a fraction of the n_upper it is launched for)
-    if (c->trace_mode == RT_TRACE_EXACT)
-        k = c->exact_rays_per_lane ? c->exact_rays_per_lane
-                                   : (n_upper >= (form == 1 ? 1 << 18 : 1 << 21) ? 8 : (k < 2 ? 2 : k));
+    // (the all-pairs kernel holds rays in pairs; eight per lane amortise each LDS read of a triangle best)
+    const bool exact = c->trace_mode == RT_TRACE_EXACT;
+    if (exact) k = c->exact_rays_per_lane ? c->exact_rays_per_lane : (n_upper >= (1 << 18) ? 8 : (k < 2 ? 2 : k));
     const int ray_blocks = cdiv(n_upper, BLOCK * k);
     const int tiles = cdiv(p.tri_end - p.tri_begin, TILE);
     if (ray_blocks <= 0 || tiles <= 0) return RT_OK;
-    p.tiles_per_y = pick_tiles_per_y(ray_blocks, tiles);
+    // (a list of bounce rays is a fraction of the n_upper it is launched for -- an eighth, say -- and the
+    // workgroups beyond its end leave at once: the all-pairs mode cuts the triangles finer to make up for them)
+    p.tiles_per_y = pick_tiles_per_y(exact && form == 0 ? (ray_blocks + 7) / 8 : ray_blocks, tiles);
     // sub-ranges start on multiples of the larger (cone) tile
     p.tiles_per_y = (p.tiles_per_y + CONE_TILE / TILE - 1) / (CONE_TILE / TILE) * (CONE_TILE / TILE);
     // the shared-origin form queues pairs as (slot - first slot of the sub-range) * 2048 + ray in 32 bits
     if (p.tiles_per_y > (1 << 21) / TILE) p.tiles_per_y = (1 << 21) / TILE;
     const dim3 grid(ray_blocks, cdiv(tiles, p.tiles_per_y));
     size_t ks;
-    if (int r = klog_begin(c, stage, form, k, c->trace_mode == RT_TRACE_EXACT, n_slot, (unsigned long long)n_upper,
+    if (int r = klog_begin(c, stage, form, k, exact, n_slot, (unsigned long long)n_upper,
                            (unsigned long long)(p.tri_end - p.tri_begin), &ks))
         return r;
 #define RT_DISPATCH(KK)                                                             \
