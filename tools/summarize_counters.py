@@ -49,11 +49,13 @@ for f in ("pmc_sq/sq", "pmc_fetch/f", "pmc_write/w", "pmc_misc/m"):
             continue
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         calls[(k, f)].add(r["Dispatch_Id"])
-# one whole frame of the counter run: the dispatches from one whole-frame raygen up to the next
+# one whole frame of the counter run: the dispatches from one whole-frame primary traversal up to the next
+# (rt_render leaves raygen to that kernel, so it is the first kernel of a frame)
 frame = None
 sq_rows = list(csv.DictReader(open(f"{base}/pmc_sq/sq_counter_collection.csv")))
-gen = sorted({int(r["Dispatch_Id"]) for r in sq_rows if short(r["Kernel_Name"]) == "rtk::raygen_kernel"
-              and int(r["Grid_Size"]) == max(int(q["Grid_Size"]) for q in sq_rows if short(q["Kernel_Name"]) == "rtk::raygen_kernel")})
+FIRST = "rtk::traverse_grid_kernel<false>"
+gen = sorted({int(r["Dispatch_Id"]) for r in sq_rows if short(r["Kernel_Name"]) == FIRST
+              and int(r["Grid_Size"]) == max(int(q["Grid_Size"]) for q in sq_rows if short(q["Kernel_Name"]) == FIRST)})
 if len(gen) >= 4:
     lo, hi = gen[2], gen[3]
     sel = [r for r in sq_rows if lo <= int(r["Dispatch_Id"]) < hi]
