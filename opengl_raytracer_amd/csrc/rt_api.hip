@@ -452,7 +452,8 @@ extern "C" int rt_create(rt_ctx **out, int hip_device, int width, int height)
     CRCHK(hipMalloc(&c->list, c->cap * sizeof(int)));
     CRCHK(hipMalloc(&c->walk_slot_d, c->cap * sizeof(int)));
     CRCHK(hipMalloc(&c->walk_t_d, c->cap * sizeof(float)));
-    CRCHK(hipMalloc(&c->walk_count_d, sizeof(int)));
+    CRCHK(hipMalloc(&c->walk_count_d, 2 * sizeof(int))); // [1]: the walk's hand-out counter
+    CRCHK(hipMemsetAsync(c->walk_count_d, 0, 2 * sizeof(int), c->stream));
     CRCHK(hipMalloc(&c->alist[0], c->cap * sizeof(int)));
     CRCHK(hipMalloc(&c->alist[1], c->cap * sizeof(int)));
     for (int k = 0; k < 2; k++)
@@ -1464,6 +1465,7 @@ static int launch_traverse_clustered(rt_ctx *c, TraverseParams p, int n_upper, i
         p.walk_slot = c->walk_slot_d;
         p.walk_t = c->walk_t_d;
         p.walk_count = c->walk_count_d;
+        p.walk_next = c->walk_count_d + 1;
         p.walk_budget = c->walk_budget;
         // (walk_count_d was zeroed by the kernel of this stage call that prepared the slots)
         // a fixed number of wavefronts, each with a run of the list (fewer when even the longest list there

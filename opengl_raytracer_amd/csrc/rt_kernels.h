@@ -739,6 +739,7 @@ struct TraverseParams {
     int *walk_slot;
     float *walk_t;
     int *walk_count;
+    int *walk_next;  // traverse_voxel_kernel: the next slot no wavefront has taken yet (zero when the launch starts)
     int walk_budget; // loop steps of a wavefront before it hands over the walks still under way (0: from the list's length)
 };
 
@@ -2618,11 +2619,20 @@ __global__ __launch_bounds__(BLOCK) void traverse_voxel_kernel(TraverseParams p)
     // walk has ended takes the next ray of the run (when VOXEL_REFILL_MIN lanes are free: taking a ray
     // costs the wavefront a start-up sequence).  The launch has a fixed number of wavefronts; the runs are
     // as long as the list needs.
-    const int n_waves = (int)gridDim.x * (BLOCK / 64);
-    const int run = (((n + n_waves - 1) / n_waves) + 63) & ~63;
-    int nxt = (blockIdx.x * (BLOCK / 64) + (tid >> 6)) * run;
-    if (nxt >= n) return; // the whole wavefront
-    const int c1 = min(nxt + run, n);
+    // (the rays are handed out 64 at a time from a counter shared by the launch: equal runs per wavefront end
+    // at very different times -- the mean wavefront lived 0.6 of the launch -- because walks differ so much)
+    int nxt = 0, c1 = 0;
+    bool exhausted = false;
+    auto grab = [&]() {
+        int base = 0;
+        if ((tid & 63) == 0) base = atomicAdd(p.walk_next, 64);
+        base = __builtin_amdgcn_readfirstlane(base);
+        exhausted = base >= n;
+        nxt = exhausted ? n : base;
+        c1 = min(nxt + 64, n);
+    };
+    grab();
+    if (exhausted) return; // the whole wavefront
     const int budget = p.walk_budget > 0 ? p.walk_budget : (n >= (1 << 19) ? 96 : 48);
     const rtv::Grid &G = p.vox;
 
@@ -2701,6 +2711,7 @@ __global__ __launch_bounds__(BLOCK) void traverse_voxel_kernel(TraverseParams p)
     for (;;) {
         // ---- lanes whose walk has ended hand in their ray and take the next one of the run
         const unsigned long long idle = __builtin_amdgcn_ballot_w64(!active);
+        if (nxt >= c1 && !exhausted && (idle == ~0ull || __popcll(idle) >= VOXEL_REFILL_MIN)) grab();
         if (idle == ~0ull || (nxt < c1 && __popcll(idle) >= VOXEL_REFILL_MIN)) {
             if (any64(!active && cand >= 0)) flush();
             if (have && !active) {
@@ -2837,6 +2848,8 @@ __global__ __launch_bounds__(BLOCK) void traverse_voxel_long_kernel(TraversePara
     unsigned int *s_start = s_start_all[wave];
     float *s_enter = s_enter_all[wave];
     const int n = *p.walk_count;
+    // (the per-lane walk before this launch has finished: its hand-out counter returns to zero for its next launch)
+    if (blockIdx.x == 0 && threadIdx.x == 0) *p.walk_next = 0;
     const rtv::Grid &G = p.vox;
     const int n_waves = (int)gridDim.x * (BLOCK / 64);
     unsigned long long n_cand = 0, n_slow = 0;
