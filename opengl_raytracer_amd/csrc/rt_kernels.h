@@ -2620,7 +2620,9 @@ __global__ __launch_bounds__(BLOCK) void traverse_voxel_kernel(TraverseParams p)
     // costs the wavefront a start-up sequence).  The launch has a fixed number of wavefronts; the runs are
     // as long as the list needs.
     // (the rays are handed out 64 at a time from a counter shared by the launch: equal runs per wavefront end
-    // at very different times -- the mean wavefront lived 0.6 of the launch -- because walks differ so much)
+    // at very different times -- the mean wavefront lived 0.6 of the launch -- because walks differ so much.
+    // A list that gives the launch's wavefronts at most 64 rays each is dealt out once and for all: more
+    // wavefronts with a ray per lane finish sooner than fewer that take a second helping.)
     int nxt = 0, c1 = 0;
     bool exhausted = false;
     auto grab = [&]() {
@@ -2631,9 +2633,16 @@ __global__ __launch_bounds__(BLOCK) void traverse_voxel_kernel(TraverseParams p)
         nxt = exhausted ? n : base;
         c1 = min(nxt + 64, n);
     };
-    grab();
-    if (exhausted) return; // the whole wavefront
-    const int budget = p.walk_budget > 0 ? p.walk_budget : (n >= (1 << 19) ? 96 : 48);
+    const int n_waves = (int)gridDim.x * (BLOCK / 64);
+    if (n > 64 * n_waves) {
+        grab();
+    } else {
+        nxt = (blockIdx.x * (BLOCK / 64) + (tid >> 6)) * 64;
+        c1 = min(nxt + 64, n);
+        exhausted = true;
+    }
+    if (nxt >= n) return; // the whole wavefront
+    const int budget = p.walk_budget > 0 ? p.walk_budget : (n >= (1 << 18) ? 96 : 48);
     const rtv::Grid &G = p.vox;
 
     // per-lane state of the ray in hand
