@@ -162,6 +162,9 @@ struct rt_ctx {
     unsigned long long *build_count_d = nullptr; // [0] pairs the list builder counted, [1] its fault flag,
                                                  // [2], [3]: grid_overflow_kernel
     unsigned int *build_overflow_d = nullptr;    // a bit per slot: the builder had no room for one of its pairs
+    unsigned int *build_item_keys_d = nullptr;   // the builder's items (grid_list_kernel): cells two levels up ...
+    int *build_item_vals_d = nullptr;            // ... and their slots; build_count_d[4] counts them
+    size_t build_items_cap = 0;
     unsigned long long *build_feedback_h = nullptr; // pinned, per origin: [0], [1] of its last build (never waited for)
     unsigned int *build_keys_d = nullptr, *build_keys_out_d = nullptr; // (cell, slot) pairs before / after the sort
     int *build_vals_d = nullptr;
@@ -492,8 +495,8 @@ extern "C" int rt_create(rt_ctx **out, int hip_device, int width, int height)
     CRCHK(hipMalloc(&c->count_d, 8 * sizeof(int)));
     CRCHK(hipHostMalloc(&c->count_h, 8 * sizeof(int)));
     CRCHK(hipHostMalloc(&c->feedback_h, 4 * sizeof(int)));
-    CRCHK(hipHostMalloc(&c->build_feedback_h, 2 * (1 + RT_MAX_LIGHTS) * sizeof(unsigned long long)));
-    memset(c->build_feedback_h, 0, 2 * (1 + RT_MAX_LIGHTS) * sizeof(unsigned long long));
+    CRCHK(hipHostMalloc(&c->build_feedback_h, 6 * (1 + RT_MAX_LIGHTS) * sizeof(unsigned long long)));
+    memset(c->build_feedback_h, 0, 6 * (1 + RT_MAX_LIGHTS) * sizeof(unsigned long long));
     c->feedback_h[0] = -1;
     CRCHK(hipMalloc(&c->sum_d, sizeof(unsigned long long)));
     CRCHK(hipHostMalloc(&c->sum_h, sizeof(unsigned long long)));
@@ -581,6 +584,8 @@ extern "C" void rt_destroy(rt_ctx *c)
     (void)hipFree(c->slot_views_d);
     (void)hipFree(c->build_count_d);
     (void)hipFree(c->build_overflow_d);
+    (void)hipFree(c->build_item_keys_d);
+    (void)hipFree(c->build_item_vals_d);
     if (c->build_feedback_h) (void)hipHostFree(c->build_feedback_h);
     (void)hipFree(c->build_keys_d);
     (void)hipFree(c->build_keys_out_d);
@@ -817,7 +822,7 @@ extern "C" int rt_set_mesh(rt_ctx *c, const rt_vertex *vertices, int num_vertice
     c->band_cells_pending = false;
     (void)hipFree(c->slot_views_d); c->slot_views_d = nullptr;
     (void)hipFree(c->build_overflow_d); c->build_overflow_d = nullptr;
-    memset(c->build_feedback_h, 0, 2 * (1 + RT_MAX_LIGHTS) * sizeof(unsigned long long)); // counts of another mesh
+    memset(c->build_feedback_h, 0, 6 * (1 + RT_MAX_LIGHTS) * sizeof(unsigned long long)); // counts of another mesh
     c->num_vertices = num_vertices;
     c->num_tris = num_vertices / 3;
     {
@@ -1541,12 +1546,14 @@ static int build_grid(rt_ctx *c, int which, const rtf::ConeRec *cones, const rtf
     // frame -- does not wait: it runs in the arrays there are, every kernel after it takes the count from
     // the device, and the count comes back to the host on its own (pinned memory), where the NEXT build of
     // the origin reads it and, when the arrays have become tight, waits once and enlarges them.
-    if (!c->build_count_d) HIPCHK(c, hipMalloc(&c->build_count_d, 4 * sizeof(unsigned long long)));
+    if (!c->build_count_d) HIPCHK(c, hipMalloc(&c->build_count_d, 6 * sizeof(unsigned long long)));
     if (!c->build_overflow_d) HIPCHK(c, hipMalloc(&c->build_overflow_d, ((size_t)c->num_slots / 32 + 1) * sizeof(unsigned int)));
-    volatile unsigned long long *fb = c->build_feedback_h + 2 * which; // [0] pairs of this origin's last build, [1] fault
+    // what this origin's last build counted: [0] pairs, [1] fault, [4] items
+    volatile unsigned long long *fb = c->build_feedback_h + 6 * which;
     if (fb[1] != 0) return fail(c, RT_ERR_HIP, "direction cells: the list builder ran out of stack");
     const size_t seen = (size_t)fb[0];
     bool wait = !c->grid_entries[which] || !c->build_keys_d || seen == 0 || seen + seen / 8 > c->build_pairs_cap ||
+                (size_t)fb[4] > c->build_items_cap ||
                 c->grid_cap[which] < c->build_pairs_cap + (size_t)c->num_slots ||
                 c->build_pairs_cap + (size_t)c->num_slots >= ((size_t)1 << 31);
     if (getenv("RT_LIST_REPORT")) // diagnostic: how this build runs, and what the origin's last build counted
@@ -1560,20 +1567,37 @@ static int build_grid(rt_ctx *c, int which, const rtf::ConeRec *cones, const rtf
             HIPCHK(c, hipMalloc(&c->build_keys_d, room * sizeof(unsigned int)));
             HIPCHK(c, hipMalloc(&c->build_keys_out_d, room * sizeof(unsigned int)));
             HIPCHK(c, hipMalloc(&c->build_vals_d, room * sizeof(int)));
+            // items: (cell two levels up, slot) of the wavefronts with heavy slots -- a sixteenth of the pairs they
+            // stand for, so a quarter of the pairs' room is ample (what does not fit goes the overflow's way)
+            (void)hipFree(c->build_item_keys_d); c->build_item_keys_d = nullptr;
+            (void)hipFree(c->build_item_vals_d); c->build_item_vals_d = nullptr;
+            if (c->build_items_cap < c->build_pairs_cap / 4 + 4096) c->build_items_cap = c->build_pairs_cap / 4 + 4096;
+            HIPCHK(c, hipMalloc(&c->build_item_keys_d, c->build_items_cap * sizeof(unsigned int)));
+            HIPCHK(c, hipMalloc(&c->build_item_vals_d, c->build_items_cap * sizeof(int)));
         }
-        HIPCHK(c, hipMemsetAsync(c->build_count_d, 0, 4 * sizeof(unsigned long long), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->build_count_d, 0, 6 * sizeof(unsigned long long), c->stream));
         HIPCHK(c, hipMemsetAsync(c->build_overflow_d, 0, ((size_t)c->num_slots / 32 + 1) * sizeof(unsigned int), c->stream));
-        hipLaunchKernelGGL(grid_list_kernel, dim3(cdiv(c->num_slots, GRID_LIST_WAVES * 64)), dim3(GRID_LIST_WAVES * 64), 0,
-                           c->stream, (const rtg::CellCone *)c->cell_cones_d, level,
+        const GridItems items{c->build_item_keys_d, c->build_item_vals_d, c->build_count_d + 4,
+                              (unsigned long long)c->build_items_cap};
+        hipLaunchKernelGGL((grid_list_kernel<false>), dim3(cdiv(c->num_slots, GRID_LIST_WAVES * 64)),
+                           dim3(GRID_LIST_WAVES * 64), 0, c->stream, (const rtg::CellCone *)c->cell_cones_d, level,
                            (const rtg::SlotView *)c->slot_views_d, c->num_slots, c->build_keys_d, c->build_vals_d,
                            c->build_count_d, (unsigned long long)c->build_pairs_cap,
-                           reinterpret_cast<int *>(c->build_count_d + 1), c->build_overflow_d);
+                           reinterpret_cast<int *>(c->build_count_d + 1), c->build_overflow_d, items);
+        HIPCHK(c, hipGetLastError());
+        // the items of wavefronts with heavy slots, 64 to a wavefront (their number is on the device: wavefronts
+        // beyond it leave at once)
+        hipLaunchKernelGGL((grid_list_kernel<true>), dim3(cdiv((long long)c->build_items_cap, GRID_LIST_WAVES * 64)),
+                           dim3(GRID_LIST_WAVES * 64), 0, c->stream, (const rtg::CellCone *)c->cell_cones_d, level,
+                           (const rtg::SlotView *)c->slot_views_d, c->num_slots, c->build_keys_d, c->build_vals_d,
+                           c->build_count_d, (unsigned long long)c->build_pairs_cap,
+                           reinterpret_cast<int *>(c->build_count_d + 1), c->build_overflow_d, items);
         HIPCHK(c, hipGetLastError());
         hipLaunchKernelGGL(grid_overflow_kernel, dim3(cdiv(c->num_slots, BLOCK)), dim3(BLOCK), 0, c->stream,
                            (const unsigned int *)c->build_overflow_d, c->num_slots, (unsigned int)ncells, c->build_keys_d,
                            c->build_vals_d, c->build_count_d, (unsigned long long)c->build_pairs_cap);
         HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipMemcpyAsync((void *)fb, c->build_count_d, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync((void *)fb, c->build_count_d, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
         if (!wait) {
             total = c->build_pairs_cap + (size_t)c->num_slots; // an upper bound: the kernels read the count themselves
             break;
@@ -1584,13 +1608,18 @@ static int build_grid(rt_ctx *c, int which, const rtf::ConeRec *cones, const rtf
             return fail(c, RT_ERR_NOMEM, "direction cells: %llu list entries for one origin exceed the 32-bit list "
                         "positions; lower RT_OPT_GRID_BITS", (unsigned long long)fb[0]);
         total = (size_t)fb[0];
-        // (room to spare, so that the builds that follow without waiting stay inside the arrays)
-        if (total + total / 4 <= c->build_pairs_cap || (attempt && total <= c->build_pairs_cap)) break;
-        if (attempt > 1) return fail(c, RT_ERR_HIP, "direction cells: the list builder counted %zu pairs twice over", total);
+        const size_t n_items = (size_t)fb[4];
+        // (room to spare, so that the builds that follow without waiting stay inside the arrays; items that did
+        // not fit took their pairs out of the count, so the build is repeated with room for them)
+        if (n_items <= c->build_items_cap &&
+            (total + total / 4 <= c->build_pairs_cap || (attempt && total <= c->build_pairs_cap)))
+            break;
+        if (attempt > 2) return fail(c, RT_ERR_HIP, "direction cells: the list builder counted %zu pairs three times over", total);
         (void)hipFree(c->build_keys_d); c->build_keys_d = nullptr;
         (void)hipFree(c->build_keys_out_d); c->build_keys_out_d = nullptr;
         (void)hipFree(c->build_vals_d); c->build_vals_d = nullptr;
-        c->build_pairs_cap = total + total / 2 + 1024;
+        if (n_items > c->build_items_cap) c->build_items_cap = n_items + n_items / 2 + 1024;
+        if (total + total / 4 > c->build_pairs_cap) c->build_pairs_cap = total + total / 2 + 1024;
     }
     if (c->grid_cap[which] < c->build_pairs_cap + (size_t)c->num_slots || !c->grid_entries[which]) {
         (void)hipFree(c->grid_entries[which]);

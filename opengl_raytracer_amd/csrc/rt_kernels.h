@@ -1424,10 +1424,26 @@ constexpr int GRID_LIST_STACK = 1024;
 constexpr int GRID_LIST_RESERVE = 40;
 constexpr int GRID_LIST_OUT = 256;        // pairs a wavefront gathers before it appends them
 constexpr int GRID_LIST_STAGE_PITCH = 13; // 16-byte pieces per node in the staging area: 12 + 1 against bank conflicts
+//   Two phases, so that a few slots that cover thousands of cells -- large triangles next to the origin --
+// do not leave the launch to the handful of wavefronts that hold them.  A wavefront one of whose slots is
+// HEAVY (its cone spans more than GRID_LIST_HEAVY_CELLS finest cells, or it has planes but no cone) stops two
+// levels above the finest and appends what it has there, (cell of that level, slot), to a list of ITEMS
+// instead; a second launch (ITEMS = true) takes the items 64 to a wavefront -- a lane's "slot" is then its
+// item's slot, its root the item's cell -- and walks the last two levels.  Wavefronts without a heavy slot
+// go all the way down themselves.  An item the list has no room for marks its slot in overflow[].
+constexpr int GRID_LIST_ITEM_LEVELS = 2;
+constexpr double GRID_LIST_HEAVY_CELLS = 96.0;
+struct GridItems {
+    unsigned int *keys; // cell of level (bits - GRID_LIST_ITEM_LEVELS)
+    int *vals;          // slot
+    unsigned long long *cursor;
+    unsigned long long cap;
+};
+template <bool ITEMS>
 __global__ __launch_bounds__(GRID_LIST_WAVES * 64) void grid_list_kernel(
     const rtg::CellCone *__restrict__ cells, int bits, const rtg::SlotView *__restrict__ views, int num_slots,
     unsigned int *__restrict__ keys, int *__restrict__ vals, unsigned long long *__restrict__ cursor,
-    unsigned long long cap, int *__restrict__ fault, unsigned int *__restrict__ overflow)
+    unsigned long long cap, int *__restrict__ fault, unsigned int *__restrict__ overflow, GridItems items)
 {
     static_assert(sizeof(rtg::CellCone) == 48, "four cones are twelve 16-byte pieces");
     __shared__ unsigned int stack_all[GRID_LIST_WAVES][GRID_LIST_STACK];
@@ -1437,7 +1453,9 @@ __global__ __launch_bounds__(GRID_LIST_WAVES * 64) void grid_list_kernel(
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
     const int first = (blockIdx.x * GRID_LIST_WAVES + wave) * 64;
-    if (first >= num_slots) return;
+    // (ITEMS: the number of items is what the first launch counted, at most what there was room for)
+    const int n_in = ITEMS ? (int)min(*items.cursor, items.cap) : num_slots;
+    if (first >= n_in) return;
     unsigned int *stack = stack_all[wave]; // node: item | level << 6 | cell << 10
     unsigned int *okey = okey_all[wave];
     int *oval = oval_all[wave];
@@ -1449,15 +1467,19 @@ __global__ __launch_bounds__(GRID_LIST_WAVES * 64) void grid_list_kernel(
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
+    bool to_items = false; // wave-uniform: the output buffer holds items, not pairs
     auto flush = [&]() {
         if (!n_out) return;
+        unsigned int *kout = to_items ? items.keys : keys;
+        int *vout = to_items ? items.vals : vals;
+        const unsigned long long room = to_items ? items.cap : cap;
         unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(cursor, (unsigned long long)n_out);
+        if (lane == 0) base = atomicAdd(to_items ? items.cursor : cursor, (unsigned long long)n_out);
         base = __shfl(base, 0, 64);
         for (int k = lane; k < n_out; k += 64)
-            if (base + (unsigned long long)k < cap) {
-                keys[base + k] = okey[k];
-                vals[base + k] = oval[k];
+            if (base + (unsigned long long)k < room) {
+                kout[base + k] = okey[k];
+                vout[base + k] = oval[k];
             } else {
                 atomicOr(&overflow[oval[k] >> 5], 1u << (oval[k] & 31));
             }
@@ -1471,8 +1493,15 @@ __global__ __launch_bounds__(GRID_LIST_WAVES * 64) void grid_list_kernel(
                   "the view travels between lanes as 18 doubles");
     double md[18];
     for (int i = 0; i < 18; i++) md[i] = 0.0;
-    if (first + lane < num_slots) {
-        const double2 *vp = reinterpret_cast<const double2 *>(views + first + lane);
+    // the slot this lane holds: its own (first + lane), or its item's
+    int my_slot = first + lane;
+    unsigned int my_cell = 0;
+    if (ITEMS && first + lane < n_in) {
+        my_slot = items.vals[first + lane];
+        my_cell = items.keys[first + lane];
+    }
+    if (first + lane < n_in) {
+        const double2 *vp = reinterpret_cast<const double2 *>(views + my_slot);
         for (int i = 0; i < 9; i++) {
             const double2 d = vp[i];
             md[2 * i] = d.x;
@@ -1493,7 +1522,14 @@ __global__ __launch_bounds__(GRID_LIST_WAVES * 64) void grid_list_kernel(
         return v;
     };
     const rtg::SlotView mine = view_of(md);
-    {
+    int leaf_level = bits; // children of this level are written out, not expanded
+    if (ITEMS) {
+        // root: the item's cell, two levels above the finest
+        const bool walk = first + lane < n_in;
+        const unsigned long long mw = __builtin_amdgcn_ballot_w64(walk);
+        if (walk) stack[lanes_below(mw)] = (unsigned int)lane | ((unsigned int)(bits - GRID_LIST_ITEM_LEVELS) << 6) | (my_cell << 10);
+        sp = __popcll(mw);
+    } else {
         const bool everywhere = mine.cone != 0 && rtg::slot_everywhere(mine);
         const bool walk = mine.cone != 0 && !everywhere;
         const unsigned long long me = __builtin_amdgcn_ballot_w64(everywhere);
@@ -1502,6 +1538,15 @@ __global__ __launch_bounds__(GRID_LIST_WAVES * 64) void grid_list_kernel(
             oval[lanes_below(me)] = first + lane;
         }
         n_out = __popcll(me);
+        // a heavy slot: its cone spans many of the finest cells (solid angle 2 pi (1 - cos) of 4 pi, over 4^bits
+        // cells), or it has no cone to say
+        const bool heavy = walk && (mine.cone == 2 || (1.0 - mine.ct) * 0.5 * (double)num_cells > GRID_LIST_HEAVY_CELLS);
+        if (bits - GRID_LIST_ITEM_LEVELS >= 3 && items.cap > 0 && any64(heavy)) {
+            wave_sync();
+            flush(); // (the pairs of the list "everywhere" are pairs)
+            to_items = true;
+            leaf_level = bits - GRID_LIST_ITEM_LEVELS;
+        }
         // roots: the four cells of level 1 (not tested themselves: the tables start at level 2)
         const unsigned long long mw = __builtin_amdgcn_ballot_w64(walk);
         if (walk)
@@ -1576,14 +1621,15 @@ __global__ __launch_bounds__(GRID_LIST_WAVES * 64) void grid_list_kernel(
                 cc.psi = got[3 * k + 2].y;
                 pass[k] = rtg::cell_meets_slot(cc, view);
             }
-        const bool leaf = level == bits;
+        const bool leaf = level == leaf_level;
+        const int slot_of_item = __shfl(my_slot, (int)item, 64);
         for (int k = 0; k < 4; k++) {
             const unsigned long long mp = __builtin_amdgcn_ballot_w64(pass[k] && !leaf);
             const unsigned long long mo = __builtin_amdgcn_ballot_w64(pass[k] && leaf);
             if (pass[k] && !leaf) stack[sp + lanes_below(mp)] = item | ((unsigned int)level << 6) | ((cell4 + (unsigned int)k) << 10);
             if (pass[k] && leaf) {
                 okey[n_out + lanes_below(mo)] = cell4 + (unsigned int)k;
-                oval[n_out + lanes_below(mo)] = first + (int)item;
+                oval[n_out + lanes_below(mo)] = slot_of_item;
             }
             sp += __popcll(mp);
             n_out += __popcll(mo);
@@ -1599,8 +1645,9 @@ __global__ __launch_bounds__(GRID_LIST_WAVES * 64) void grid_list_kernel(
     flush();
 }
 
-// After grid_list_kernel: the slots it had no room for go on the list "everywhere" (key num_cells), once
-// each, behind the `cap` pairs that were stored; counts[3] receives the number of pairs there are to sort.
+// After grid_list_kernel: the slots it had no room for (a pair beyond `cap`, or an item beyond the items' room)
+// go on the list "everywhere" (key num_cells), once each, behind the pairs that were stored; counts[3] receives
+// the number of pairs there are to sort.
 // counts: [0] pairs grid_list_kernel counted, [2] marked slots filed so far, [3] the result (all zero but
 // [0] when the launch starts).
 __global__ __launch_bounds__(BLOCK) void grid_overflow_kernel(const unsigned int *__restrict__ overflow, int num_slots,
@@ -1609,11 +1656,12 @@ __global__ __launch_bounds__(BLOCK) void grid_overflow_kernel(const unsigned int
                                                               unsigned long long cap)
 {
     const unsigned long long total = counts[0];
+    const unsigned long long stored = total < cap ? total : cap;
     const int slot = blockIdx.x * BLOCK + threadIdx.x;
-    if (slot == 0) atomicAdd(&counts[3], total < cap ? total : cap);
-    if (total <= cap || slot >= num_slots) return;
+    if (slot == 0) atomicAdd(&counts[3], stored);
+    if (slot >= num_slots) return;
     if ((overflow[slot >> 5] >> (slot & 31)) & 1u) {
-        const unsigned long long pos = cap + atomicAdd(&counts[2], 1ull);
+        const unsigned long long pos = stored + atomicAdd(&counts[2], 1ull);
         keys[pos] = num_cells;
         vals[pos] = slot;
         atomicAdd(&counts[3], 1ull);
