@@ -162,7 +162,7 @@ struct rt_ctx {
     unsigned long long *build_count_d = nullptr; // [0] pairs the list builder counted, [1] its fault flag,
                                                  // [2], [3]: grid_overflow_kernel
     unsigned int *build_overflow_d = nullptr;    // a bit per slot: the builder had no room for one of its pairs
-    unsigned int *build_item_keys_d = nullptr;   // the builder's items (grid_list_kernel): cells two levels up ...
+    unsigned int *build_item_keys_d = nullptr;   // the builder's items (grid_list_kernel): cells three levels up ...
     int *build_item_vals_d = nullptr;            // ... and their slots; build_count_d[4] counts them
     size_t build_items_cap = 0;
     unsigned long long *build_feedback_h = nullptr; // pinned, per origin: [0], [1] of its last build (never waited for)
@@ -1567,7 +1567,7 @@ static int build_grid(rt_ctx *c, int which, const rtf::ConeRec *cones, const rtf
             HIPCHK(c, hipMalloc(&c->build_keys_d, room * sizeof(unsigned int)));
             HIPCHK(c, hipMalloc(&c->build_keys_out_d, room * sizeof(unsigned int)));
             HIPCHK(c, hipMalloc(&c->build_vals_d, room * sizeof(int)));
-            // items: (cell two levels up, slot) of the wavefronts with heavy slots -- a sixteenth of the pairs they
+            // items: (cell three levels up, slot) of the wavefronts with heavy slots -- far fewer than the pairs they
             // stand for, so a quarter of the pairs' room is ample (what does not fit goes the overflow's way)
             (void)hipFree(c->build_item_keys_d); c->build_item_keys_d = nullptr;
             (void)hipFree(c->build_item_vals_d); c->build_item_vals_d = nullptr;

@@ -1426,12 +1426,12 @@ constexpr int GRID_LIST_OUT = 256;        // pairs a wavefront gathers before it
 constexpr int GRID_LIST_STAGE_PITCH = 13; // 16-byte pieces per node in the staging area: 12 + 1 against bank conflicts
 //   Two phases, so that a few slots that cover thousands of cells -- large triangles next to the origin --
 // do not leave the launch to the handful of wavefronts that hold them.  A wavefront one of whose slots is
-// HEAVY (its cone spans more than GRID_LIST_HEAVY_CELLS finest cells, or it has planes but no cone) stops two
+// HEAVY (its cone spans more than GRID_LIST_HEAVY_CELLS finest cells, or it has planes but no cone) stops three
 // levels above the finest and appends what it has there, (cell of that level, slot), to a list of ITEMS
 // instead; a second launch (ITEMS = true) takes the items 64 to a wavefront -- a lane's "slot" is then its
-// item's slot, its root the item's cell -- and walks the last two levels.  Wavefronts without a heavy slot
+// item's slot, its root the item's cell -- and walks the last three levels (64 finest cells per item).  Wavefronts without a heavy slot
 // go all the way down themselves.  An item the list has no room for marks its slot in overflow[].
-constexpr int GRID_LIST_ITEM_LEVELS = 2;
+constexpr int GRID_LIST_ITEM_LEVELS = 3;
 constexpr double GRID_LIST_HEAVY_CELLS = 96.0;
 struct GridItems {
     unsigned int *keys; // cell of level (bits - GRID_LIST_ITEM_LEVELS)
@@ -1524,7 +1524,7 @@ __global__ __launch_bounds__(GRID_LIST_WAVES * 64) void grid_list_kernel(
     const rtg::SlotView mine = view_of(md);
     int leaf_level = bits; // children of this level are written out, not expanded
     if (ITEMS) {
-        // root: the item's cell, two levels above the finest
+        // root: the item's cell, three levels above the finest
         const bool walk = first + lane < n_in;
         const unsigned long long mw = __builtin_amdgcn_ballot_w64(walk);
         if (walk) stack[lanes_below(mw)] = (unsigned int)lane | ((unsigned int)(bits - GRID_LIST_ITEM_LEVELS) << 6) | (my_cell << 10);
