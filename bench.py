@@ -16,10 +16,11 @@ Two ways to shard (--sharding):
   batch  every rank renders whole frames: the 64-view workload deals its fixed set of views over the
          ranks ("strong", its default); a single-frame workload renders one frame per rank ("weak").
 
-Frames in flight (--frames-in-flight, default 3): every rank renders with that many contexts, which take the
-frames (views) of the sequence in turn on streams of their own, so that the kernel chains of consecutive
-frames overlap on the GPU; a step is still one frame (one batch of views), the time is the wall time of the
-K steps.  After the timed region one context alone renders a few more frames for the per-kernel figures.
+Frames in flight (--frames-in-flight, default 4, one per hardware queue of the process): every rank
+renders with that many contexts, which take the frames (views) of the sequence in turn on streams of
+their own, so that the kernel chains of consecutive frames overlap on the GPU; a step is still one
+frame (one batch of views), the time is the wall time of the K steps.  After the timed region one
+context alone renders a few more frames for the per-kernel figures.
 
 value = rays actually traced (closest-hit rays entering traversal + shadow rays traced, summed over
 passes and ranks) per second of wall time, in Mrays/s.  Rays that missed everything are dead (the
@@ -58,6 +59,9 @@ PEAK_UNFUSED_TFLOPS = PEAK_FP32_TFLOPS / 2.0
 RAY_PLANE_BYTES = 56.0        # raygen writes 14 float planes per ray
 PIXEL_BYTES = 4.0             # color writes one RGBA8 pixel per ray
 VISIBLE_GATHER_BYTES = 96.0 + 4.0  # three 32-byte vertices and a texel for a pixel some light reaches
+# Contexts that take the frames in turn: one per hardware queue a process has (GPU_MAX_HW_QUEUES, 4 by HIP's
+# default); measured 2/3/4/5/6 contexts: 5.63/5.39/5.32/5.56/5.47 ms a frame of soup64k_4k_p6.
+FRAMES_IN_FLIGHT = 4
 METRIC = "Mrays/s (primary+secondary) at 4K vs triangle count; % FP32 VALU peak"
 
 # rocprof names of the traversal kernels, by (stage, form) of the library's kernel log
@@ -375,7 +379,7 @@ def main(stand_in=None):
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="contexts per GPU that take the frames (or views) of the sequence in turn, each on a stream "
                          "of its own, so that the kernel chains of consecutive frames overlap (1: one frame at a time; "
-                         "0: 3; with more than one, each context runs the two sweeps of a bounce pass in turn on its one "
+                         "0: 4; with more than one, each context runs the two sweeps of a bounce pass in turn on its one "
                          "stream instead of side by side on two -- the frames beside it fill the GPU, and a process has "
                          "four hardware queues)")
     ap.add_argument("--kernel-timing", action="store_true",
@@ -433,7 +437,7 @@ def main(stand_in=None):
     wl = workload(args.workload)
     free_before = torch.cuda.mem_get_info(dev)[0] if on_gpu else 0
     # frames in flight need framebuffers on the device (pixels that go through the host are copied in turn)
-    in_flight = args.frames_in_flight if args.frames_in_flight > 0 else 3
+    in_flight = args.frames_in_flight if args.frames_in_flight > 0 else FRAMES_IN_FLIGHT
     if not (on_gpu and shard_dev.type == "cuda"):
         in_flight = 1
     if on_gpu:
