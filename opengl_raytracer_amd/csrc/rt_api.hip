@@ -1578,16 +1578,22 @@ static int build_grid(rt_ctx *c, int which, const rtf::ConeRec *cones, const rtf
         HIPCHK(c, hipMemsetAsync(c->build_count_d, 0, 6 * sizeof(unsigned long long), c->stream));
         HIPCHK(c, hipMemsetAsync(c->build_overflow_d, 0, ((size_t)c->num_slots / 32 + 1) * sizeof(unsigned int), c->stream));
         const GridItems items{c->build_item_keys_d, c->build_item_vals_d, c->build_count_d + 4,
-                              (unsigned long long)c->build_items_cap};
+                              (unsigned long long)c->build_items_cap, GRID_LIST_HEAVY_CELLS};
         hipLaunchKernelGGL((grid_list_kernel<false>), dim3(cdiv(c->num_slots, GRID_LIST_WAVES * 64)),
                            dim3(GRID_LIST_WAVES * 64), 0, c->stream, (const rtg::CellCone *)c->cell_cones_d, level,
                            (const rtg::SlotView *)c->slot_views_d, c->num_slots, c->build_keys_d, c->build_vals_d,
                            c->build_count_d, (unsigned long long)c->build_pairs_cap,
                            reinterpret_cast<int *>(c->build_count_d + 1), c->build_overflow_d, items);
         HIPCHK(c, hipGetLastError());
-        // the items of wavefronts with heavy slots, 64 to a wavefront (their number is on the device: wavefronts
-        // beyond it leave at once)
-        hipLaunchKernelGGL((grid_list_kernel<true>), dim3(cdiv((long long)c->build_items_cap, GRID_LIST_WAVES * 64)),
+        // the items of the heavy slots, 64 to a wavefront.  Their number is on the device; the launch is sized
+        // by twice what the origin's last build counted (by the room there is when this build waits anyway),
+        // wavefronts beyond the number leave at once and, should there be more, each takes several runs
+        long long item_blocks = cdiv((long long)c->build_items_cap, GRID_LIST_WAVES * 64);
+        if (!wait) {
+            const long long guess = cdiv(2 * (long long)fb[4] + 4096, GRID_LIST_WAVES * 64);
+            if (guess < item_blocks) item_blocks = guess;
+        }
+        hipLaunchKernelGGL((grid_list_kernel<true>), dim3((unsigned int)item_blocks),
                            dim3(GRID_LIST_WAVES * 64), 0, c->stream, (const rtg::CellCone *)c->cell_cones_d, level,
                            (const rtg::SlotView *)c->slot_views_d, c->num_slots, c->build_keys_d, c->build_vals_d,
                            c->build_count_d, (unsigned long long)c->build_pairs_cap,

@@ -1425,19 +1425,24 @@ constexpr int GRID_LIST_RESERVE = 40;
 constexpr int GRID_LIST_OUT = 256;        // pairs a wavefront gathers before it appends them
 constexpr int GRID_LIST_STAGE_PITCH = 13; // 16-byte pieces per node in the staging area: 12 + 1 against bank conflicts
 //   Two phases, so that a few slots that cover thousands of cells -- large triangles next to the origin --
-// do not leave the launch to the handful of wavefronts that hold them.  A wavefront one of whose slots is
-// HEAVY (its cone spans more than GRID_LIST_HEAVY_CELLS finest cells, or it has planes but no cone) stops three
-// levels above the finest and appends what it has there, (cell of that level, slot), to a list of ITEMS
+// do not leave the launch to the handful of wavefronts that hold them.  The walk of a HEAVY slot (its cone
+// spans more than GRID_LIST_HEAVY_CELLS finest cells, or it has planes but no cone) stops three levels above
+// the finest, and the nodes it has there, (cell of that level, slot), are appended to a list of ITEMS
 // instead; a second launch (ITEMS = true) takes the items 64 to a wavefront -- a lane's "slot" is then its
-// item's slot, its root the item's cell -- and walks the last three levels (64 finest cells per item).  Wavefronts without a heavy slot
-// go all the way down themselves.  An item the list has no room for marks its slot in overflow[].
+// item's slot, its root the item's cell -- and walks the last three levels (64 finest cells per item).  The
+// other slots of the same wavefront go all the way down where they are.  An item the list has no room for
+// marks its slot in overflow[].
 constexpr int GRID_LIST_ITEM_LEVELS = 3;
-constexpr double GRID_LIST_HEAVY_CELLS = 96.0;
+// (threshold 96 / 1024 / 4096 / 16384 cells: 64 views of 256K triangles 51.5 / 50.1 / 49.6 / 49.9 ms a batch, the
+// 165-triangle sword with moving lights 0.385 / 0.392 / 0.396 / 0.402 ms a frame, 1.03 with cone-less slots alone)
+constexpr double GRID_LIST_HEAVY_CELLS = 1024.0;
+constexpr int GRID_LIST_ITEMS_OUT = 64;   // items a wavefront gathers before it appends them
 struct GridItems {
     unsigned int *keys; // cell of level (bits - GRID_LIST_ITEM_LEVELS)
     int *vals;          // slot
     unsigned long long *cursor;
     unsigned long long cap;
+    double heavy_cells;
 };
 template <bool ITEMS>
 __global__ __launch_bounds__(GRID_LIST_WAVES * 64) void grid_list_kernel(
@@ -1449,41 +1454,46 @@ __global__ __launch_bounds__(GRID_LIST_WAVES * 64) void grid_list_kernel(
     __shared__ unsigned int stack_all[GRID_LIST_WAVES][GRID_LIST_STACK];
     __shared__ unsigned int okey_all[GRID_LIST_WAVES][GRID_LIST_OUT + 256];
     __shared__ int oval_all[GRID_LIST_WAVES][GRID_LIST_OUT + 256];
+    __shared__ unsigned int ikey_all[GRID_LIST_WAVES][ITEMS ? 1 : GRID_LIST_ITEMS_OUT + 256];
+    __shared__ int ival_all[GRID_LIST_WAVES][ITEMS ? 1 : GRID_LIST_ITEMS_OUT + 256];
     __shared__ double2 stage_all[GRID_LIST_WAVES][16 * GRID_LIST_STAGE_PITCH];
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
-    const int first = (blockIdx.x * GRID_LIST_WAVES + wave) * 64;
-    // (ITEMS: the number of items is what the first launch counted, at most what there was room for)
+    // (ITEMS: the number of items is what the first launch counted, at most what there was room for; the launch
+    // is sized by a guess of that number, so a wavefront goes on to further runs of 64 items while there are any)
     const int n_in = ITEMS ? (int)min(*items.cursor, items.cap) : num_slots;
-    if (first >= n_in) return;
+    for (int first = (blockIdx.x * GRID_LIST_WAVES + wave) * 64; first < n_in; first += (int)gridDim.x * GRID_LIST_WAVES * 64) {
     unsigned int *stack = stack_all[wave]; // node: item | level << 6 | cell << 10
     unsigned int *okey = okey_all[wave];
     int *oval = oval_all[wave];
+    unsigned int *ikey = ikey_all[wave];
+    int *ival = ival_all[wave];
     double2 *stage = stage_all[wave];
     const unsigned int num_cells = 1u << (2 * bits);
-    int sp = 0, n_out = 0; // wave-uniform
+    int sp = 0, n_out = 0, n_items_out = 0; // wave-uniform
     auto wave_sync = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
-    bool to_items = false; // wave-uniform: the output buffer holds items, not pairs
-    auto flush = [&]() {
-        if (!n_out) return;
-        unsigned int *kout = to_items ? items.keys : keys;
-        int *vout = to_items ? items.vals : vals;
-        const unsigned long long room = to_items ? items.cap : cap;
+    auto append = [&](const unsigned int *bk, const int *bv, int &n, unsigned int *kout, int *vout,
+                      unsigned long long *cur, unsigned long long room) {
+        if (!n) return;
         unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(to_items ? items.cursor : cursor, (unsigned long long)n_out);
+        if (lane == 0) base = atomicAdd(cur, (unsigned long long)n);
         base = __shfl(base, 0, 64);
-        for (int k = lane; k < n_out; k += 64)
+        for (int k = lane; k < n; k += 64)
             if (base + (unsigned long long)k < room) {
-                kout[base + k] = okey[k];
-                vout[base + k] = oval[k];
+                kout[base + k] = bk[k];
+                vout[base + k] = bv[k];
             } else {
-                atomicOr(&overflow[oval[k] >> 5], 1u << (oval[k] & 31));
+                atomicOr(&overflow[bv[k] >> 5], 1u << (bv[k] & 31));
             }
-        n_out = 0;
+        n = 0;
+    };
+    auto flush = [&]() { append(okey, oval, n_out, keys, vals, cursor, cap); };
+    auto flush_items = [&]() {
+        if (!ITEMS) append(ikey, ival, n_items_out, items.keys, items.vals, items.cursor, items.cap);
     };
 
     // this lane's slot: its view as 18 doubles (the first holds the two flags)
@@ -1522,7 +1532,7 @@ __global__ __launch_bounds__(GRID_LIST_WAVES * 64) void grid_list_kernel(
         return v;
     };
     const rtg::SlotView mine = view_of(md);
-    int leaf_level = bits; // children of this level are written out, not expanded
+    bool my_heavy = false; // this lane's slot stops three levels up and goes on as items
     if (ITEMS) {
         // root: the item's cell, three levels above the finest
         const bool walk = first + lane < n_in;
@@ -1540,13 +1550,8 @@ __global__ __launch_bounds__(GRID_LIST_WAVES * 64) void grid_list_kernel(
         n_out = __popcll(me);
         // a heavy slot: its cone spans many of the finest cells (solid angle 2 pi (1 - cos) of 4 pi, over 4^bits
         // cells), or it has no cone to say
-        const bool heavy = walk && (mine.cone == 2 || (1.0 - mine.ct) * 0.5 * (double)num_cells > GRID_LIST_HEAVY_CELLS);
-        if (bits - GRID_LIST_ITEM_LEVELS >= 3 && items.cap > 0 && any64(heavy)) {
-            wave_sync();
-            flush(); // (the pairs of the list "everywhere" are pairs)
-            to_items = true;
-            leaf_level = bits - GRID_LIST_ITEM_LEVELS;
-        }
+        my_heavy = walk && bits - GRID_LIST_ITEM_LEVELS >= 3 && items.cap > 0 &&
+                   (mine.cone == 2 || (1.0 - mine.ct) * 0.5 * (double)num_cells > items.heavy_cells);
         // roots: the four cells of level 1 (not tested themselves: the tables start at level 2)
         const unsigned long long mw = __builtin_amdgcn_ballot_w64(walk);
         if (walk)
@@ -1621,18 +1626,30 @@ __global__ __launch_bounds__(GRID_LIST_WAVES * 64) void grid_list_kernel(
                 cc.psi = got[3 * k + 2].y;
                 pass[k] = rtg::cell_meets_slot(cc, view);
             }
-        const bool leaf = level == leaf_level;
+        // children of the finest level are pairs; those of a heavy slot three levels above it are items
+        const bool heavy_node = !ITEMS && __shfl((int)my_heavy, (int)item, 64) != 0;
+        const bool leaf = level == bits;
+        const bool hand_on = heavy_node && level == bits - GRID_LIST_ITEM_LEVELS;
         const int slot_of_item = __shfl(my_slot, (int)item, 64);
         for (int k = 0; k < 4; k++) {
-            const unsigned long long mp = __builtin_amdgcn_ballot_w64(pass[k] && !leaf);
+            const unsigned long long mp = __builtin_amdgcn_ballot_w64(pass[k] && !leaf && !hand_on);
             const unsigned long long mo = __builtin_amdgcn_ballot_w64(pass[k] && leaf);
-            if (pass[k] && !leaf) stack[sp + lanes_below(mp)] = item | ((unsigned int)level << 6) | ((cell4 + (unsigned int)k) << 10);
+            if (pass[k] && !leaf && !hand_on)
+                stack[sp + lanes_below(mp)] = item | ((unsigned int)level << 6) | ((cell4 + (unsigned int)k) << 10);
             if (pass[k] && leaf) {
                 okey[n_out + lanes_below(mo)] = cell4 + (unsigned int)k;
                 oval[n_out + lanes_below(mo)] = slot_of_item;
             }
             sp += __popcll(mp);
             n_out += __popcll(mo);
+            if (!ITEMS) {
+                const unsigned long long mi = __builtin_amdgcn_ballot_w64(pass[k] && hand_on);
+                if (pass[k] && hand_on) {
+                    ikey[n_items_out + lanes_below(mi)] = cell4 + (unsigned int)k;
+                    ival[n_items_out + lanes_below(mi)] = slot_of_item;
+                }
+                n_items_out += __popcll(mi);
+            }
         }
         if (sp > GRID_LIST_STACK - 4) { // cannot happen (see above)
             if (lane == 0) *fault = 1;
@@ -1640,9 +1657,14 @@ __global__ __launch_bounds__(GRID_LIST_WAVES * 64) void grid_list_kernel(
         }
         wave_sync();
         if (n_out >= GRID_LIST_OUT) flush();
+        if (n_items_out >= GRID_LIST_ITEMS_OUT) flush_items();
     }
     wave_sync();
     flush();
+    flush_items();
+    wave_sync();
+    if (!ITEMS) break; // (slots: one run of 64 per wavefront)
+    }
 }
 
 // After grid_list_kernel: the slots it had no room for (a pair beyond `cap`, or an item beyond the items' room)
