@@ -2671,8 +2671,6 @@ __global__ __launch_bounds__(BLOCK) void traverse_bandcell_kernel(TraverseParams
 // ---------------------------------------------------------------------------
 constexpr int VOXEL_FLUSH_MIN = 16;
 constexpr int VOXEL_BATCH = rtv::LIST_ALIGN; // triangles of a cell's list a lane takes per step of its loop
-constexpr int VOXEL_SEEN = 32; // per lane: triangles remembered as already tested (a triangle is on the lists of
-                               // all the cells around it, and a ray meets it in several of them in a row)
 constexpr int VOXEL_REFILL_MIN = 16; // free lanes that make a wavefront take new rays
 constexpr int VOXEL_WAVES = 4096;    // wavefronts of a launch of the walk (four per SIMD)
 
@@ -2680,8 +2678,6 @@ __global__ __launch_bounds__(BLOCK) void traverse_voxel_kernel(TraverseParams p)
 {
     constexpr int B = VOXEL_BATCH;
     static_assert(B == 4, "a group of list entries is one int4");
-    // seen[h][lane]: the last triangle with index = h (mod VOXEL_SEEN) this lane put through the filter
-    __shared__ int seen[VOXEL_SEEN][BLOCK];
     const int tid = threadIdx.x;
     const int n = p.count ? *p.count : p.n;
     // The wavefront's rays: a run of consecutive slots, [nxt, c1).  Walks differ in length by an order of
@@ -2734,11 +2730,13 @@ __global__ __launch_bounds__(BLOCK) void traverse_voxel_kernel(TraverseParams p)
     // [idx, end) is what is left of the current cell's list after the batch in `tri`; `enter` is the
     // parameter at which the cell of that batch was entered.
     unsigned int idx = 0, end = 0, n_idx = 0, n_end = 0;
+    unsigned int came_from = 0u, n_came_from = 0u; // entries with this flag were tested in the cell before (rt_voxel.h)
     bool more = false;
     float n_enter = 0.0f, enter = 0.0f;
     auto look_ahead = [&]() {
         more = rtv::walk_step(G, ox, oy, oz, w);
         n_enter = w.t_enter;
+        n_came_from = w.came_from;
         if (more) {
             const int cell = rtv::cell_index(G, w);
             n_idx = p.vox_off[cell];
@@ -2756,6 +2754,7 @@ __global__ __launch_bounds__(BLOCK) void traverse_voxel_kernel(TraverseParams p)
                 idx = n_idx;
                 end = n_end;
                 enter = n_enter;
+                came_from = n_came_from;
                 look_ahead();
             }
         }
@@ -2764,13 +2763,19 @@ __global__ __launch_bounds__(BLOCK) void traverse_voxel_kernel(TraverseParams p)
         if (active && idx < end) grp = *reinterpret_cast<const int4 *>(p.vox_entries + idx);
         tri[0] = grp.x; tri[1] = grp.y; tri[2] = grp.z; tri[3] = grp.w;
 #pragma unroll
-        for (int k = 0; k < B; k++) has[k] = tri[k] >= 0;
+        for (int k = 0; k < B; k++) {
+            has[k] = tri[k] >= 0 && !rtv::entry_tested_before(tri[k], came_from);
+            tri[k] &= rtv::ENTRY_TRI_MASK;
+        }
         idx += B;
     };
 #pragma unroll
     for (int k = 0; k < B; k++) { tri[k] = -1; has[k] = false; }
     int cand = -1;
     unsigned long long n_cand = 0, n_slow = 0, n_rays = 0;
+#ifdef RT_WALK_STATS
+    unsigned long long st_a = 0, st_b = 0;
+#endif
 
     // the reference arithmetic on every lane's candidate
     auto flush = [&]() {
@@ -2826,8 +2831,6 @@ __global__ __launch_bounds__(BLOCK) void traverse_voxel_kernel(TraverseParams p)
                 const unsigned long long key = p.best[sl];
                 tbest = tfirst = __uint_as_float((unsigned int)(key >> 32));
                 idbest = idfirst = (int)(unsigned int)(key & 0xffffffffull);
-#pragma unroll
-                for (int h = 0; h < VOXEL_SEEN; h++) seen[h][tid] = -1;
                 have = true;
                 gave_up = false;
                 own_steps = 0;
@@ -2842,6 +2845,7 @@ __global__ __launch_bounds__(BLOCK) void traverse_voxel_kernel(TraverseParams p)
                     idx = p.vox_off[cell];
                     end = p.vox_off[cell + 1];
                     enter = w.t_enter;
+                    came_from = 0u; // the first cell: nothing has been tested yet
                     look_ahead();
                 }
                 next_batch();
@@ -2864,14 +2868,15 @@ __global__ __launch_bounds__(BLOCK) void traverse_voxel_kernel(TraverseParams p)
         for (int k = 0; k < B; k++) {
             cur[k] = tri[k];
             cur_has[k] = has[k] && active;
-            if (cur_has[k]) {
-                int *slot = &seen[cur[k] & (VOXEL_SEEN - 1)][tid];
-                if (*slot == cur[k]) cur_has[k] = false;
-                else *slot = cur[k];
-            }
             const float4 *rp = reinterpret_cast<const float4 *>(p.recs + (cur_has[k] ? cur[k] : 0));
             r0[k] = rp[0]; r1[k] = rp[1]; r2[k] = rp[2];
+#ifdef RT_WALK_STATS
+            st_b += __popcll(__builtin_amdgcn_ballot_w64(RT_WALK_STATS == 1 ? cur_has[k] : (has[k] && active)));
+#endif
         }
+#ifdef RT_WALK_STATS
+        st_a += RT_WALK_STATS == 1 ? __popcll(__builtin_amdgcn_ballot_w64(active)) : 64;
+#endif
         // ... and, in the same round trip, the indices of the next
         next_batch();
         bool pass[B];
@@ -2899,6 +2904,10 @@ __global__ __launch_bounds__(BLOCK) void traverse_voxel_kernel(TraverseParams p)
         add_counter(p.counters, C_CH_CAND, n_cand);
         add_counter(p.counters, C_CH_SLOW, n_slow);
         add_counter(p.counters, C_CH_PAIRS, n_rays * (unsigned long long)p.num_tris);
+#ifdef RT_WALK_STATS
+        add_counter(p.counters, 10, st_a);
+        add_counter(p.counters, 11, st_b);
+#endif
     }
 }
 
@@ -3034,7 +3043,7 @@ __global__ __launch_bounds__(BLOCK) void traverse_voxel_long_kernel(TraversePara
                 }
                 unsigned long long mine = ~0ull;
                 if (has && !rtv::walk_done_at(G, w.inv_dn, s_enter[c], tb)) {
-                    const int tri = p.vox_entries[s_start[c] + (unsigned int)(e - s_first[c])]; // -1: padding
+                    const int tri = rtv::entry_triangle(p.vox_entries[s_start[c] + (unsigned int)(e - s_first[c])]); // -1: padding
                     const float4 *rp = reinterpret_cast<const float4 *>(p.recs + (tri < 0 ? 0 : tri));
                     const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
                     const float rec[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};

@@ -62,6 +62,18 @@ struct Grid {         // (named members, not arrays: an axis chosen per lane mus
 
 constexpr float STOP_FACTOR = 0.94f;
 constexpr int LIST_ALIGN = 4; // entries of a cell's list come in groups of this many (padded with -1)
+// An entry of a cell's list: the triangle's index in its low 24 bits and, above them, six flags that say
+// on which of the cell's six face neighbours' lists the triangle stands as well (bit 2a: the neighbour one
+// cell down along axis a, bit 2a + 1: one cell up).  A walk that enters a cell through a face has just been
+// through the neighbour behind that face and has put that cell's whole list to the test, so it skips the
+// entries flagged for that neighbour: by induction over the cells of the walk every triangle of every list
+// on the way is tested in the first cell of an unbroken run of cells that list it.  (A triangle's cells are
+// those that meet a convex body, so such runs are rarely broken; a broken run costs a second test, never a
+// missed one.)  Nothing is skipped in the cell a walk starts in.
+constexpr int ENTRY_FLAG_SHIFT = 24;
+constexpr int ENTRY_TRI_MASK = (1 << ENTRY_FLAG_SHIFT) - 1;
+constexpr int MAX_TRIANGLES = 1 << ENTRY_FLAG_SHIFT;
+RT_HD int entry_triangle(int e) { return e < 0 ? -1 : (e & ENTRY_TRI_MASK); }
 
 RT_HD float plane_at(const Grid &G, float gmin, int i) { return fmaf((float)i, G.cs, gmin); }
 
@@ -71,7 +83,10 @@ struct Walk {
     float invx, invy, invz;  // 1 / d per axis; its sign is the step's direction
     float t_enter;           // parameter at which the current cell was entered
     float inv_dn;            // 1 / |d|
+    unsigned int came_from;  // the entry flag of the face neighbour the walk came from (0 in its first cell)
 };
+// true: the walk has tested this entry's triangle in the cell it came from
+RT_HD bool entry_tested_before(int e, unsigned int came_from) { return ((unsigned int)e & came_from) != 0u; }
 
 RT_HD int cell_index(const Grid &G, const Walk &w) { return (w.iz * G.ny + w.iy) * G.nx + w.ix; }
 
@@ -117,6 +132,7 @@ RT_HD bool walk_start(const Grid &G, float ox, float oy, float oz, float dx, flo
     if (!clip_axis(oy, dy, w.invy, fy, G.gminy, G.gmaxy, t0, t1)) return false;
     if (!clip_axis(oz, dz, w.invz, fz, G.gminz, G.gmaxz, t0, t1)) return false;
     if (!(t0 <= t1)) return false;
+    w.came_from = 0u;
     w.t_enter = t0;
     w.ix = start_index(fmaf(t0, dx, ox), G.gminx, G.inv_cs, G.nx);
     w.iy = start_index(fmaf(t0, dy, oy), G.gminy, G.inv_cs, G.ny);
@@ -147,6 +163,8 @@ RT_HD bool walk_step(const Grid &G, float ox, float oy, float oz, Walk &w)
     w.t_enter = sx ? tx : (sy ? ty : tz);
     const bool up = inv > 0.0f;
     i += up ? 1 : -1;
+    // (going up along an axis the cell left behind is the neighbour one cell down, and the other way round)
+    w.came_from = 1u << (ENTRY_FLAG_SHIFT + (sx ? 0 : (sy ? 2 : 4)) + (up ? 0 : 1));
     // as exit_param() forms it
     const float tn = (fmaf((float)(up ? i + 1 : i), G.cs, gm) - o) * inv;
     w.ix = sx ? i : ix; w.tx = sx ? tn : tx;
@@ -242,7 +260,7 @@ RT_HD int seq_exit_event(const AxisSeq &s)
 struct VoxelSet {
     Grid grid{};
     std::vector<uint32_t> off;     // cells + 1; every list starts on a multiple of LIST_ALIGN entries
-    std::vector<int32_t> entries;  // triangle indices, cell after cell, each list padded with -1
+    std::vector<int32_t> entries;  // entries (triangle | neighbour flags), cell after cell, each list padded with -1
     double rho_max = 0.0;
     double margin = 0.0;
 };
@@ -349,8 +367,11 @@ inline void build(const rt_vertex *v, int num_tris, const std::vector<double> &r
 
     // (cell, triangle) pairs, then a counting sort by cell
     std::vector<uint32_t> cells;
-    std::vector<int32_t> tris;
+    std::vector<int32_t> tris; // entries: triangle | neighbour flags
     std::vector<uint32_t> cnt(ncell + 1, 0u);
+    std::vector<uint32_t> mine; // the cells of one triangle, ascending
+    std::vector<int> mine_xyz;
+    if (num_tris > MAX_TRIANGLES) num_tris = 0; // (the caller leaves such meshes to its other sweeps)
     for (int t = 0; t < num_tris; t++) {
         if (!(rho[t] >= 0.0)) continue;
         const double g = rho[t] + out.margin;
@@ -365,6 +386,8 @@ inline void build(const rt_vertex *v, int num_tris, const std::vector<double> &r
             c1[a] = std::max(0, std::min(gn[a] - 1, (int)std::floor((h + g - (double)gmin[a]) / cs)));
         }
         const double hh[3] = {0.5 * cs + g, 0.5 * cs + g, 0.5 * cs + g};
+        mine.clear();
+        mine_xyz.clear();
         for (int iz = c0[2]; iz <= c1[2]; iz++)
             for (int iy = c0[1]; iy <= c1[1]; iy++)
                 for (int ix = c0[0]; ix <= c1[0]; ix++) {
@@ -378,10 +401,21 @@ inline void build(const rt_vertex *v, int num_tris, const std::vector<double> &r
                     }
                     if (!tri_box_overlap(a, b, c, hh)) continue;
                     const uint32_t cell = (uint32_t)(((size_t)iz * gn[1] + iy) * gn[0] + ix);
-                    cells.push_back(cell);
-                    tris.push_back(t);
-                    cnt[cell + 1]++;
+                    mine.push_back(cell);
+                    mine_xyz.push_back(ix); mine_xyz.push_back(iy); mine_xyz.push_back(iz);
                 }
+        const uint32_t stride[3] = {1u, (uint32_t)gn[0], (uint32_t)gn[0] * (uint32_t)gn[1]};
+        for (size_t j = 0; j < mine.size(); j++) {
+            int32_t flags = 0;
+            for (int a = 0; a < 3; a++) {
+                const int i = mine_xyz[3 * j + a];
+                if (i > 0 && std::binary_search(mine.begin(), mine.end(), mine[j] - stride[a])) flags |= 1 << (2 * a);
+                if (i + 1 < gn[a] && std::binary_search(mine.begin(), mine.end(), mine[j] + stride[a])) flags |= 2 << (2 * a);
+            }
+            cells.push_back(mine[j]);
+            tris.push_back(t | (flags << ENTRY_FLAG_SHIFT));
+            cnt[mine[j] + 1]++;
+        }
     }
     // lists are padded to whole groups of LIST_ALIGN entries: a lane reads a group with one 16-byte load
     for (size_t i = 0; i < ncell; i++)

@@ -208,7 +208,7 @@ extern "C" void fm_check_clustered(int n_tris, const float *verts, int n_rays, c
                     do {
                         const int cell = rtv::cell_index(G, w);
                         for (uint32_t e = vs.off[cell]; e < vs.off[cell + 1]; e++) {
-                            const int t = vs.entries[e];
+                            const int t = rtv::entry_triangle(vs.entries[e]);
                             if (t < 0) continue; // padding
                             if (!visited[t]) { visited[t] = 1; touched.push_back(t); }
                         }
@@ -265,8 +265,10 @@ extern "C" void fm_check_clustered(int n_tris, const float *verts, int n_rays, c
                         cells_n++;
                         const int cell = rtv::cell_index(G, w);
                         for (uint32_t e = vs.off[cell]; e < vs.off[cell + 1]; e++) {
-                            const int k = vs.entries[e];
+                            const int k = rtv::entry_triangle(vs.entries[e]);
                             if (k < 0) continue; // padding
+                            // (as the kernel walks: a triangle the cell just left lists as well was tested there)
+                            if (rtv::entry_tested_before(vs.entries[e], w.came_from)) continue;
                             tests_n++;
                             if (!(rtf::filter_general(grec[k].v, o[0], o[1], o[2], d[0] * gg, d[1] * gg, d[2] * gg) >= -1.0f))
                                 continue;
