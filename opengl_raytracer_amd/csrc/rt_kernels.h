@@ -2730,17 +2730,16 @@ __global__ __launch_bounds__(BLOCK) void traverse_voxel_kernel(TraverseParams p)
     // [idx, end) is what is left of the current cell's list after the batch in `tri`; `enter` is the
     // parameter at which the cell of that batch was entered.
     unsigned int idx = 0, end = 0, n_idx = 0, n_end = 0;
-    unsigned int came_from = 0u, n_came_from = 0u; // entries with this flag were tested in the cell before (rt_voxel.h)
     bool more = false;
     float n_enter = 0.0f, enter = 0.0f;
     auto look_ahead = [&]() {
         more = rtv::walk_step(G, ox, oy, oz, w);
         n_enter = w.t_enter;
-        n_came_from = w.came_from;
         if (more) {
-            const int cell = rtv::cell_index(G, w);
-            n_idx = p.vox_off[cell];
-            n_end = p.vox_off[cell + 1];
+            // (the list of what the cell holds beyond the cell the walk comes from: rt_voxel.h)
+            const int at = rtv::list_index(G, w);
+            n_idx = p.vox_off[at];
+            n_end = p.vox_off[at + 1];
         }
     };
     int tri[B];
@@ -2754,18 +2753,18 @@ __global__ __launch_bounds__(BLOCK) void traverse_voxel_kernel(TraverseParams p)
                 idx = n_idx;
                 end = n_end;
                 enter = n_enter;
-                came_from = n_came_from;
                 look_ahead();
             }
         }
-        // one aligned group of the list (padding entries are -1)
-        int4 grp = make_int4(-1, -1, -1, -1);
-        if (active && idx < end) grp = *reinterpret_cast<const int4 *>(p.vox_entries + idx);
-        tri[0] = grp.x; tri[1] = grp.y; tri[2] = grp.z; tri[3] = grp.w;
+        // the next four entries of the list (lists are not padded: the load may run past the list's end, into
+        // the next list or the four spare entries behind the last)
+        struct __attribute__((packed, aligned(4))) Four { int v[4]; };
+        Four grp{{-1, -1, -1, -1}};
+        if (active && idx < end) grp = *reinterpret_cast<const Four *>(p.vox_entries + idx);
 #pragma unroll
         for (int k = 0; k < B; k++) {
-            has[k] = tri[k] >= 0 && !rtv::entry_tested_before(tri[k], came_from);
-            tri[k] &= rtv::ENTRY_TRI_MASK;
+            tri[k] = grp.v[k];
+            has[k] = idx + (unsigned int)k < end;
         }
         idx += B;
     };
@@ -2841,11 +2840,10 @@ __global__ __launch_bounds__(BLOCK) void traverse_voxel_kernel(TraverseParams p)
                 active = g > 0.0f && rtv::walk_start(G, ox, oy, oz, dx, dy, dz, w);
                 inv_dn = w.inv_dn;
                 if (active) {
-                    const int cell = rtv::cell_index(G, w);
-                    idx = p.vox_off[cell];
-                    end = p.vox_off[cell + 1];
+                    const int at = rtv::list_index(G, w); // (the first cell: its whole list)
+                    idx = p.vox_off[at];
+                    end = p.vox_off[at + 1];
                     enter = w.t_enter;
-                    came_from = 0u; // the first cell: nothing has been tested yet
                     look_ahead();
                 }
                 next_batch();
@@ -3008,8 +3006,9 @@ __global__ __launch_bounds__(BLOCK) void traverse_voxel_long_kernel(TraversePara
             unsigned int start = 0;
             int cnt = 0;
             if (my_cell >= 0) {
-                start = p.vox_off[my_cell];
-                cnt = (int)(p.vox_off[my_cell + 1] - start);
+                // (every triangle of the cell: this kernel does not keep track of where a walk came from)
+                start = p.vox_off[my_cell * rtv::CELL_STRIDE + rtv::LIST_START];
+                cnt = (int)(p.vox_off[my_cell * rtv::CELL_STRIDE + rtv::LIST_START + 1] - start);
             }
             // exclusive prefix sum of the list lengths over the lanes
             int incl = cnt;
@@ -3043,7 +3042,7 @@ __global__ __launch_bounds__(BLOCK) void traverse_voxel_long_kernel(TraversePara
                 }
                 unsigned long long mine = ~0ull;
                 if (has && !rtv::walk_done_at(G, w.inv_dn, s_enter[c], tb)) {
-                    const int tri = rtv::entry_triangle(p.vox_entries[s_start[c] + (unsigned int)(e - s_first[c])]); // -1: padding
+                    const int tri = p.vox_entries[s_start[c] + (unsigned int)(e - s_first[c])];
                     const float4 *rp = reinterpret_cast<const float4 *>(p.recs + (tri < 0 ? 0 : tri));
                     const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
                     const float rec[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};

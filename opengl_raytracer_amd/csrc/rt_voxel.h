@@ -61,20 +61,21 @@ struct Grid {         // (named members, not arrays: an axis chosen per lane mus
 };
 
 constexpr float STOP_FACTOR = 0.94f;
-constexpr int LIST_ALIGN = 4; // entries of a cell's list come in groups of this many (padded with -1)
-// An entry of a cell's list: the triangle's index in its low 24 bits and, above them, six flags that say
-// on which of the cell's six face neighbours' lists the triangle stands as well (bit 2a: the neighbour one
-// cell down along axis a, bit 2a + 1: one cell up).  A walk that enters a cell through a face has just been
-// through the neighbour behind that face and has put that cell's whole list to the test, so it skips the
-// entries flagged for that neighbour: by induction over the cells of the walk every triangle of every list
-// on the way is tested in the first cell of an unbroken run of cells that list it.  (A triangle's cells are
-// those that meet a convex body, so such runs are rarely broken; a broken run costs a second test, never a
-// missed one.)  Nothing is skipped in the cell a walk starts in.
-constexpr int ENTRY_FLAG_SHIFT = 24;
-constexpr int ENTRY_TRI_MASK = (1 << ENTRY_FLAG_SHIFT) - 1;
-constexpr int MAX_TRIANGLES = 1 << ENTRY_FLAG_SHIFT;
-RT_HD int entry_triangle(int e) { return e < 0 ? -1 : (e & ENTRY_TRI_MASK); }
-
+constexpr int LIST_ALIGN = 4; // entries a lane takes from a list at a time (one 16-byte load)
+// Every cell has SEVEN lists.  List 6 holds every triangle that comes near the cell; list f (0..5) holds those
+// of them that do NOT stand on list 6 of the face neighbour f as well (f = 2a: the neighbour one cell down
+// along axis a, f = 2a + 1: one cell up).  A walk that enters a cell through a face has just been through the
+// neighbour behind that face and has put that cell's whole list to the test, so in the new cell it reads the
+// list of what is new there: by induction over the cells of the walk every triangle of every list 6 on the way
+// is tested in the first cell of an unbroken run of cells that list it.  (A triangle's cells are those that
+// meet a convex body, so such runs are rarely broken; a broken run costs a second test, never a missed one.)
+// A walk reads list 6 in the cell it starts in.  On the 64K-triangle soup a list of new triangles holds 2
+// where the whole list holds 5, so most cells cost a walk one step of four entries instead of two.
+// off[8 cell + f] is where list f of the cell starts in `entries`, off[8 cell + f + 1] where it ends
+// (off[8 cell + 7] = off[8 (cell + 1)]); the lists are not padded.
+constexpr int CELL_LISTS = 7;
+constexpr int CELL_STRIDE = 8;
+constexpr int LIST_START = 6; // the list a walk reads in its first cell: everything
 RT_HD float plane_at(const Grid &G, float gmin, int i) { return fmaf((float)i, G.cs, gmin); }
 
 struct Walk {
@@ -83,12 +84,12 @@ struct Walk {
     float invx, invy, invz;  // 1 / d per axis; its sign is the step's direction
     float t_enter;           // parameter at which the current cell was entered
     float inv_dn;            // 1 / |d|
-    unsigned int came_from;  // the entry flag of the face neighbour the walk came from (0 in its first cell)
+    int face;                // the face neighbour the walk came from (0..5), LIST_START in its first cell
 };
-// true: the walk has tested this entry's triangle in the cell it came from
-RT_HD bool entry_tested_before(int e, unsigned int came_from) { return ((unsigned int)e & came_from) != 0u; }
 
 RT_HD int cell_index(const Grid &G, const Walk &w) { return (w.iz * G.ny + w.iy) * G.nx + w.ix; }
+// the list of the cell the walk is in that holds what it has not tested yet
+RT_HD int list_index(const Grid &G, const Walk &w) { return cell_index(G, w) * CELL_STRIDE + w.face; }
 
 // one axis of the slab clip; false: the line misses the box
 RT_HD bool clip_axis(float o, float d, float inv, bool flat, float lo, float hi, float &t0, float &t1)
@@ -132,7 +133,7 @@ RT_HD bool walk_start(const Grid &G, float ox, float oy, float oz, float dx, flo
     if (!clip_axis(oy, dy, w.invy, fy, G.gminy, G.gmaxy, t0, t1)) return false;
     if (!clip_axis(oz, dz, w.invz, fz, G.gminz, G.gmaxz, t0, t1)) return false;
     if (!(t0 <= t1)) return false;
-    w.came_from = 0u;
+    w.face = LIST_START;
     w.t_enter = t0;
     w.ix = start_index(fmaf(t0, dx, ox), G.gminx, G.inv_cs, G.nx);
     w.iy = start_index(fmaf(t0, dy, oy), G.gminy, G.inv_cs, G.ny);
@@ -164,7 +165,7 @@ RT_HD bool walk_step(const Grid &G, float ox, float oy, float oz, Walk &w)
     const bool up = inv > 0.0f;
     i += up ? 1 : -1;
     // (going up along an axis the cell left behind is the neighbour one cell down, and the other way round)
-    w.came_from = 1u << (ENTRY_FLAG_SHIFT + (sx ? 0 : (sy ? 2 : 4)) + (up ? 0 : 1));
+    w.face = (sx ? 0 : (sy ? 2 : 4)) + (up ? 0 : 1);
     // as exit_param() forms it
     const float tn = (fmaf((float)(up ? i + 1 : i), G.cs, gm) - o) * inv;
     w.ix = sx ? i : ix; w.tx = sx ? tn : tx;
@@ -259,8 +260,8 @@ RT_HD int seq_exit_event(const AxisSeq &s)
 // ---------------------------------------------------------------------------------------------
 struct VoxelSet {
     Grid grid{};
-    std::vector<uint32_t> off;     // cells + 1; every list starts on a multiple of LIST_ALIGN entries
-    std::vector<int32_t> entries;  // entries (triangle | neighbour flags), cell after cell, each list padded with -1
+    std::vector<uint32_t> off;     // CELL_STRIDE * cells + 1
+    std::vector<int32_t> entries;  // triangle indices: cell after cell, list after list
     double rho_max = 0.0;
     double margin = 0.0;
 };
@@ -330,7 +331,7 @@ inline void build(const rt_vertex *v, int num_tris, const std::vector<double> &r
         G.cs = 1.0f; G.inv_cs = 1.0f; G.back = 0.0f; G.slack = 0.0f; G.flat = 0.0f;
         gmin[0] = 1.0f; // gmin > gmax: every line misses
         store();
-        out.off.assign(2, 0u);
+        out.off.assign(CELL_STRIDE + 1, 0u);
         return;
     }
     double longest = 0.0;
@@ -367,11 +368,12 @@ inline void build(const rt_vertex *v, int num_tris, const std::vector<double> &r
 
     // (cell, triangle) pairs, then a counting sort by cell
     std::vector<uint32_t> cells;
-    std::vector<int32_t> tris; // entries: triangle | neighbour flags
-    std::vector<uint32_t> cnt(ncell + 1, 0u);
-    std::vector<uint32_t> mine; // the cells of one triangle, ascending
+    std::vector<int32_t> tris;
+    std::vector<unsigned char> absent; // per pair: bit f set = the triangle is not on the list of face neighbour f
+    std::vector<uint32_t> cnt(ncell * CELL_STRIDE + 1, 0u);
+    std::vector<uint32_t> mine; // the cells of one triangle
     std::vector<int> mine_xyz;
-    if (num_tris > MAX_TRIANGLES) num_tris = 0; // (the caller leaves such meshes to its other sweeps)
+    std::vector<unsigned char> in_box; // per cell of the triangle's box of cells, one cell of rim around it: listed?
     for (int t = 0; t < num_tris; t++) {
         if (!(rho[t] >= 0.0)) continue;
         const double g = rho[t] + out.margin;
@@ -388,6 +390,11 @@ inline void build(const rt_vertex *v, int num_tris, const std::vector<double> &r
         const double hh[3] = {0.5 * cs + g, 0.5 * cs + g, 0.5 * cs + g};
         mine.clear();
         mine_xyz.clear();
+        const int bx = c1[0] - c0[0] + 3, by = c1[1] - c0[1] + 3, bz = c1[2] - c0[2] + 3;
+        in_box.assign((size_t)bx * by * bz, 0);
+        auto box_at = [&](int ix, int iy, int iz) -> unsigned char & {
+            return in_box[((size_t)(iz - c0[2] + 1) * by + (iy - c0[1] + 1)) * bx + (ix - c0[0] + 1)];
+        };
         for (int iz = c0[2]; iz <= c1[2]; iz++)
             for (int iy = c0[1]; iy <= c1[1]; iy++)
                 for (int ix = c0[0]; ix <= c1[0]; ix++) {
@@ -403,26 +410,31 @@ inline void build(const rt_vertex *v, int num_tris, const std::vector<double> &r
                     const uint32_t cell = (uint32_t)(((size_t)iz * gn[1] + iy) * gn[0] + ix);
                     mine.push_back(cell);
                     mine_xyz.push_back(ix); mine_xyz.push_back(iy); mine_xyz.push_back(iz);
+                    box_at(ix, iy, iz) = 1;
                 }
-        const uint32_t stride[3] = {1u, (uint32_t)gn[0], (uint32_t)gn[0] * (uint32_t)gn[1]};
         for (size_t j = 0; j < mine.size(); j++) {
-            int32_t flags = 0;
-            for (int a = 0; a < 3; a++) {
-                const int i = mine_xyz[3 * j + a];
-                if (i > 0 && std::binary_search(mine.begin(), mine.end(), mine[j] - stride[a])) flags |= 1 << (2 * a);
-                if (i + 1 < gn[a] && std::binary_search(mine.begin(), mine.end(), mine[j] + stride[a])) flags |= 2 << (2 * a);
-            }
+            const int ix = mine_xyz[3 * j], iy = mine_xyz[3 * j + 1], iz = mine_xyz[3 * j + 2];
+            // bit f: the face neighbour f lists the triangle too (cells outside the grid are in the rim: not listed)
+            const int here = box_at(ix - 1, iy, iz) | box_at(ix + 1, iy, iz) << 1 | box_at(ix, iy - 1, iz) << 2 |
+                             box_at(ix, iy + 1, iz) << 3 | box_at(ix, iy, iz - 1) << 4 | box_at(ix, iy, iz + 1) << 5;
             cells.push_back(mine[j]);
-            tris.push_back(t | (flags << ENTRY_FLAG_SHIFT));
-            cnt[mine[j] + 1]++;
+            tris.push_back(t);
+            absent.push_back((unsigned char)(~here & 63));
+            for (int f = 0; f < 6; f++)
+                if (!((here >> f) & 1)) cnt[(size_t)mine[j] * CELL_STRIDE + f + 1]++;
+            cnt[(size_t)mine[j] * CELL_STRIDE + LIST_START + 1]++;
         }
     }
-    // lists are padded to whole groups of LIST_ALIGN entries: a lane reads a group with one 16-byte load
-    for (size_t i = 0; i < ncell; i++)
-        cnt[i + 1] = cnt[i] + (cnt[i + 1] + (uint32_t)LIST_ALIGN - 1) / (uint32_t)LIST_ALIGN * (uint32_t)LIST_ALIGN;
+    // counts -> positions (slot 8 cell + 7 holds nothing of its own: it is where the next cell's lists start)
+    for (size_t i = 0; i < ncell * CELL_STRIDE; i++) cnt[i + 1] += cnt[i];
     out.off = cnt;
-    out.entries.assign(cnt[ncell], -1);
+    out.entries.assign(cnt[ncell * CELL_STRIDE], -1);
     std::vector<uint32_t> cur(cnt.begin(), cnt.end() - 1);
-    for (size_t i = 0; i < cells.size(); i++) out.entries[cur[cells[i]]++] = tris[i];
+    for (size_t i = 0; i < cells.size(); i++) {
+        const size_t at = (size_t)cells[i] * CELL_STRIDE;
+        for (int f = 0; f < 6; f++)
+            if ((absent[i] >> f) & 1) out.entries[cur[at + f]++] = tris[i];
+        out.entries[cur[at + LIST_START]++] = tris[i];
+    }
 }
 } // namespace rtv

@@ -207,9 +207,9 @@ extern "C" void fm_check_clustered(int n_tris, const float *verts, int n_rays, c
                 if (rtv::walk_start(G, o[0], o[1], o[2], d[0], d[1], d[2], w)) {
                     do {
                         const int cell = rtv::cell_index(G, w);
-                        for (uint32_t e = vs.off[cell]; e < vs.off[cell + 1]; e++) {
-                            const int t = rtv::entry_triangle(vs.entries[e]);
-                            if (t < 0) continue; // padding
+                        const int at = cell * rtv::CELL_STRIDE + rtv::LIST_START; // every triangle of the cell
+                        for (uint32_t e = vs.off[at]; e < vs.off[at + 1]; e++) {
+                            const int t = vs.entries[e];
                             if (!visited[t]) { visited[t] = 1; touched.push_back(t); }
                         }
                     } while (rtv::walk_step(G, o[0], o[1], o[2], w));
@@ -263,12 +263,10 @@ extern "C" void fm_check_clustered(int n_tris, const float *verts, int n_rays, c
                 if (rtv::walk_start(G, o[0], o[1], o[2], d[0], d[1], d[2], w)) {
                     for (;;) {
                         cells_n++;
-                        const int cell = rtv::cell_index(G, w);
-                        for (uint32_t e = vs.off[cell]; e < vs.off[cell + 1]; e++) {
-                            const int k = rtv::entry_triangle(vs.entries[e]);
-                            if (k < 0) continue; // padding
-                            // (as the kernel walks: a triangle the cell just left lists as well was tested there)
-                            if (rtv::entry_tested_before(vs.entries[e], w.came_from)) continue;
+                        // (as the kernel walks: the list of what the cell holds beyond the cell just left)
+                        const int at = rtv::list_index(G, w);
+                        for (uint32_t e = vs.off[at]; e < vs.off[at + 1]; e++) {
+                            const int k = vs.entries[e];
                             tests_n++;
                             if (!(rtf::filter_general(grec[k].v, o[0], o[1], o[2], d[0] * gg, d[1] * gg, d[2] * gg) >= -1.0f))
                                 continue;
