@@ -11,7 +11,7 @@
 //   * the build lists triangle k in every cell that comes within rho_k + m of it (m: the margin that
 //     covers the walk's rounding, below), so the cell that holds P lists k;
 //   * P = o + t d with t >= -0.22 rho / |d| (a computed t^ > 0 forces that, see the bound on t^ below),
-//     so a walk that starts rho_max + m behind the origin and visits every cell the line crosses from
+//     so a walk that starts 0.25 rho_max + m behind the origin and visits every cell the line crosses from
 //     there on meets the cell of P;
 //   * for a pair of kind (A) the computed t^ and the exact t are tied by
 //         t^ >= 0.948 t - 0.0523 min(|e1|,|e2|) / |d|        (t >= 0)
@@ -55,7 +55,7 @@ struct Grid {         // (named members, not arrays: an axis chosen per lane mus
     float cs;        // edge length of the (cubic) cells
     float inv_cs;
     int nx, ny, nz;  // cells per axis
-    float back;      // distance: the walk starts this far behind the ray's origin (rho_max + margin)
+    float back;      // distance: the walk starts this far behind the ray's origin (0.25 rho_max + margin)
     float slack;     // distance: 0.25 rho_max, the absolute term of the bound on t^
     float flat;      // an axis with |d_axis| <= |d| * flat is not stepped
 };
@@ -115,7 +115,7 @@ RT_HD int start_index(float p, float gmin, float inv_cs, int n)
     return (int)q;
 }
 
-// Places the walk in the cell where the line enters the grid, or rho_max + margin behind the ray's
+// Places the walk in the cell where the line enters the grid, or 0.25 rho_max + margin behind the ray's
 // origin, or at parameter t_from (a walk taken up again: the parameter at which it had entered the
 // cell it was in; -inf for a new walk), whichever comes last.  false: the line misses the grid, or
 // the ray is not one the walk handles (zero or non-finite direction).
@@ -361,7 +361,8 @@ inline void build(const rt_vertex *v, int num_tris, const std::vector<double> &r
     double diag = 0.0;
     for (int a = 0; a < 3; a++) diag += ((double)gmax[a] - gmin[a]) * ((double)gmax[a] - gmin[a]);
     diag = std::sqrt(diag) + pad;
-    G.back = (float)(out.rho_max + out.margin);
+    G.back = (float)(0.25 * out.rho_max * 1.001 + out.margin);
+    if ((double)G.back < 0.25 * out.rho_max + out.margin) G.back = std::nextafterf(G.back, INFINITY);
     G.slack = (float)(0.25 * out.rho_max * 1.001);
     if ((double)G.slack < 0.25 * out.rho_max) G.slack = std::nextafterf(G.slack, INFINITY);
     G.flat = (float)(0.25 * out.margin / diag);
