@@ -159,7 +159,7 @@ int rt_set_trace_mode(rt_ctx *ctx, int mode /* rt_trace_mode */);
  *                           1..128, or 0 = chosen from the number of triangles (default 0)
  *   RT_OPT_WALK_BUDGET      loop steps a wavefront of that walk spends, one ray per lane, before the walks
  *                           still under way are handed to the kernel that gives each a wavefront of its
- *                           own; 0 = chosen from the number of rays (default: 96 from 2^18 rays on, else 48)
+ *                           own; 0 = chosen from the number of rays (default: 96 from 2^18 rays on, else 32)
  *   RT_OPT_FAIL_NEXT_STAGE  for tests of a caller's error handling: with a value other than 0 the next
  *                           rt_intersect or rt_color fails with RT_ERR_HIP after it has begun (its timing
  *                           events open, nothing enqueued) and the option returns to 0

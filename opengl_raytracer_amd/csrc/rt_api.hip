@@ -175,6 +175,8 @@ struct rt_ctx {
     unsigned int *band_off = nullptr;
     int *band_entries = nullptr;
     bool band_cells_pending = false; // rt_set_mesh left them to the first clustered bounce pass
+    bool vox_pending = false;        // ... and the cells in space too (built on the host, from vox_rho)
+    std::vector<double> vox_rho;     // per triangle: the radius the cells list it with (< 0: it takes no part)
     void *bucket_frames_d = nullptr;  // rtg::BucketFrame of every finest direction cell
     int band_buckets = 0;             // origin buckets per cell and axis asked for (rt_set_option); 0: chosen here
     int band_g = 1;                   // ... and built
@@ -621,6 +623,36 @@ static int sum_counts(rt_ctx *c, const unsigned int *v, size_t n, unsigned long 
     *total = *c->sum_h;
     return RT_OK;
 }
+// The cells in space of the mesh in hand (rt_voxel.h), from the vertices on the device and the radii the cluster
+// build left behind.
+static int build_voxels(rt_ctx *c)
+{
+    (void)hipFree(c->vox_off_d); c->vox_off_d = nullptr;
+    (void)hipFree(c->vox_entries_d); c->vox_entries_d = nullptr;
+    std::vector<rt_vertex> vertices((size_t)c->num_tris * 3 + 1);
+    if (c->num_tris)
+        HIPCHK(c, hipMemcpyAsync(vertices.data(), c->verts, (size_t)c->num_tris * 3 * sizeof(rt_vertex), hipMemcpyDeviceToHost,
+                                 c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    rtv::VoxelSet vs;
+    const double abs_extent = std::sqrt((double)c->center[0] * c->center[0] + (double)c->center[1] * c->center[1] +
+                                        (double)c->center[2] * c->center[2]) + 3.0 * (double)c->radius;
+    // (a mesh of 2^21 triangles or more never takes the clustered bounce path: rt_intersect sends its
+    // bounce rays through the per-pair filter, so the cells stay empty rather than cost seconds of
+    // box/triangle tests on the host and hundreds of MB that nothing reads)
+    rtv::build(vertices.data(), c->num_tris < (1 << 21) ? c->num_tris : 0, c->vox_rho, abs_extent, c->voxel_res, vs);
+    c->vox = vs.grid;
+    HIPCHK(c, hipMalloc(&c->vox_off_d, vs.off.size() * sizeof(unsigned int)));
+    HIPCHK(c, hipMalloc(&c->vox_entries_d, (vs.entries.size() + 4) * sizeof(int)));
+    HIPCHK(c, hipMemcpyAsync(c->vox_off_d, vs.off.data(), vs.off.size() * sizeof(unsigned int), hipMemcpyHostToDevice,
+                             c->stream));
+    if (!vs.entries.empty())
+        HIPCHK(c, hipMemcpyAsync(c->vox_entries_d, vs.entries.data(), vs.entries.size() * sizeof(int),
+                                 hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream)); // vs goes out of scope
+    return RT_OK;
+}
+
 static int build_band_cells(rt_ctx *c)
 {
     if (!c->grid_bits || !c->num_ngroups) return RT_OK;
@@ -820,6 +852,8 @@ extern "C" int rt_set_mesh(rt_ctx *c, const rt_vertex *vertices, int num_vertice
     (void)hipFree(c->vox_entries_d); c->vox_entries_d = nullptr;
     drop_band_lists(c);
     c->band_cells_pending = false;
+    c->vox_pending = false;
+    c->vox_rho.clear();
     (void)hipFree(c->slot_views_d); c->slot_views_d = nullptr;
     (void)hipFree(c->build_overflow_d); c->build_overflow_d = nullptr;
     memset(c->build_feedback_h, 0, 6 * (1 + RT_MAX_LIGHTS) * sizeof(unsigned long long)); // counts of another mesh
@@ -931,25 +965,11 @@ extern "C" int rt_set_mesh(rt_ctx *c, const rt_vertex *vertices, int num_vertice
             HIPCHK(c, hipMemcpyAsync(c->nrec_d, cs.nrecs.data(), ng * rtc::NGROUP * 2 * sizeof(float4),
                                      hipMemcpyHostToDevice, c->stream));
         }
-        {
-            // the cells in space: the triangles the band records leave to the spatial sweep (rho >= 0)
-            rtv::VoxelSet vs;
-            const double abs_extent = std::sqrt((double)c->center[0] * c->center[0] + (double)c->center[1] * c->center[1] +
-                                                (double)c->center[2] * c->center[2]) + 3.0 * (double)c->radius;
-            // (a mesh of 2^21 triangles or more never takes the clustered bounce path: rt_intersect sends its
-            // bounce rays through the per-pair filter, so the cells stay empty rather than cost seconds of
-            // box/triangle tests on the host and hundreds of MB that nothing reads)
-            rtv::build(vertices, c->num_tris < (1 << 21) ? c->num_tris : 0, cs.rho, abs_extent, c->voxel_res, vs);
-            c->vox = vs.grid;
-            HIPCHK(c, hipMalloc(&c->vox_off_d, vs.off.size() * sizeof(unsigned int)));
-            HIPCHK(c, hipMalloc(&c->vox_entries_d, (vs.entries.size() + 4) * sizeof(int)));
-            HIPCHK(c, hipMemcpyAsync(c->vox_off_d, vs.off.data(), vs.off.size() * sizeof(unsigned int),
-                                     hipMemcpyHostToDevice, c->stream));
-            if (!vs.entries.empty())
-                HIPCHK(c, hipMemcpyAsync(c->vox_entries_d, vs.entries.data(), vs.entries.size() * sizeof(int),
-                                         hipMemcpyHostToDevice, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream)); // vs goes out of scope
-        }
+        // (the cells in space are built by the first bounce pass that walks them, like the band sweep's lists: a
+        // host that only traces fresh rays and shadow rays never pays for them -- seconds of box / triangle tests
+        // and 240 MB at 256K triangles)
+        c->vox_rho = cs.rho;
+        c->vox_pending = true;
         HIPCHK(c, hipStreamSynchronize(c->stream)); // the host vectors go out of scope
         // (the band sweep's lists are built by the first bounce pass that wants them: a host that only traces
         // fresh rays and shadow rays never pays for them -- 12 ms and 300 MB at 64K triangles)
@@ -1810,6 +1830,10 @@ extern "C" int rt_intersect(rt_ctx *c)
             // the first bounce pass on this mesh: the direction cells of the band sweep (waits for their size)
             c->band_cells_pending = false;
             if (int r = build_band_cells(c)) return r;
+        }
+        if (clustered && c->vox_pending) { // ... and the cells in space
+            c->vox_pending = false;
+            if (int r = build_voxels(c)) return r;
         }
         if (shared) {
             // fresh rays: all live, all through camera_pos; visited in pixel-tile order

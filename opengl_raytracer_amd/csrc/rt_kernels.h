@@ -2710,7 +2710,7 @@ __global__ __launch_bounds__(BLOCK) void traverse_voxel_kernel(TraverseParams p)
         exhausted = true;
     }
     if (nxt >= n) return; // the whole wavefront
-    const int budget = p.walk_budget > 0 ? p.walk_budget : (n >= (1 << 18) ? 96 : 48);
+    const int budget = p.walk_budget > 0 ? p.walk_budget : (n >= (1 << 18) ? 96 : 32);
     const rtv::Grid &G = p.vox;
 
     // per-lane state of the ray in hand

@@ -45,6 +45,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <thread>
 #include <vector>
 
 namespace rtv {
@@ -372,59 +373,91 @@ inline void build(const rt_vertex *v, int num_tris, const std::vector<double> &r
     std::vector<int32_t> tris;
     std::vector<unsigned char> absent; // per pair: bit f set = the triangle is not on the list of face neighbour f
     std::vector<uint32_t> cnt(ncell * CELL_STRIDE + 1, 0u);
-    std::vector<uint32_t> mine; // the cells of one triangle
-    std::vector<int> mine_xyz;
-    std::vector<unsigned char> in_box; // per cell of the triangle's box of cells, one cell of rim around it: listed?
-    for (int t = 0; t < num_tris; t++) {
-        if (!(rho[t] >= 0.0)) continue;
-        const double g = rho[t] + out.margin;
-        int c0[3], c1[3];
-        for (int a = 0; a < 3; a++) {
-            double l = v[3 * t].pos[a], h = l;
-            for (int k = 1; k < 3; k++) {
-                l = std::min(l, (double)v[3 * t + k].pos[a]);
-                h = std::max(h, (double)v[3 * t + k].pos[a]);
-            }
-            c0[a] = std::max(0, std::min(gn[a] - 1, (int)std::floor((l - g - (double)gmin[a]) / cs)));
-            c1[a] = std::max(0, std::min(gn[a] - 1, (int)std::floor((h + g - (double)gmin[a]) / cs)));
-        }
-        const double hh[3] = {0.5 * cs + g, 0.5 * cs + g, 0.5 * cs + g};
-        mine.clear();
-        mine_xyz.clear();
-        const int bx = c1[0] - c0[0] + 3, by = c1[1] - c0[1] + 3, bz = c1[2] - c0[2] + 3;
-        in_box.assign((size_t)bx * by * bz, 0);
-        auto box_at = [&](int ix, int iy, int iz) -> unsigned char & {
-            return in_box[((size_t)(iz - c0[2] + 1) * by + (iy - c0[1] + 1)) * bx + (ix - c0[0] + 1)];
-        };
-        for (int iz = c0[2]; iz <= c1[2]; iz++)
-            for (int iy = c0[1]; iy <= c1[1]; iy++)
-                for (int ix = c0[0]; ix <= c1[0]; ix++) {
-                    const double cc[3] = {(double)gmin[0] + (ix + 0.5) * cs, (double)gmin[1] + (iy + 0.5) * cs,
-                                          (double)gmin[2] + (iz + 0.5) * cs};
-                    double a[3], b[3], c[3];
-                    for (int q = 0; q < 3; q++) {
-                        a[q] = (double)v[3 * t].pos[q] - cc[q];
-                        b[q] = (double)v[3 * t + 1].pos[q] - cc[q];
-                        c[q] = (double)v[3 * t + 2].pos[q] - cc[q];
-                    }
-                    if (!tri_box_overlap(a, b, c, hh)) continue;
-                    const uint32_t cell = (uint32_t)(((size_t)iz * gn[1] + iy) * gn[0] + ix);
-                    mine.push_back(cell);
-                    mine_xyz.push_back(ix); mine_xyz.push_back(iy); mine_xyz.push_back(iz);
-                    box_at(ix, iy, iz) = 1;
+    // The box/triangle tests are most of a build (tens of millions on a large mesh): the triangles are cut into
+    // runs, a host thread per run files its pairs, and the runs are joined in order, so the lists come out the
+    // same whatever the number of threads.
+    struct Part {
+        std::vector<uint32_t> cells;
+        std::vector<int32_t> tris;
+        std::vector<unsigned char> absent;
+    };
+    unsigned int n_threads = std::thread::hardware_concurrency();
+    n_threads = std::max(1u, std::min(n_threads, 16u));
+    if (num_tris < 8192) n_threads = 1;
+    std::vector<Part> parts(n_threads);
+    auto file_run = [&](unsigned int part) {
+        Part &P = parts[part];
+        const int t_begin = (int)((long long)num_tris * part / n_threads);
+        const int t_end = (int)((long long)num_tris * (part + 1) / n_threads);
+        std::vector<uint32_t> mine; // the cells of one triangle
+        std::vector<int> mine_xyz;
+        std::vector<unsigned char> in_box; // per cell of the triangle's box of cells, one cell of rim around it: listed?
+        for (int t = t_begin; t < t_end; t++) {
+            if (!(rho[t] >= 0.0)) continue;
+            const double g = rho[t] + out.margin;
+            int c0[3], c1[3];
+            for (int a = 0; a < 3; a++) {
+                double l = v[3 * t].pos[a], h = l;
+                for (int k = 1; k < 3; k++) {
+                    l = std::min(l, (double)v[3 * t + k].pos[a]);
+                    h = std::max(h, (double)v[3 * t + k].pos[a]);
                 }
-        for (size_t j = 0; j < mine.size(); j++) {
-            const int ix = mine_xyz[3 * j], iy = mine_xyz[3 * j + 1], iz = mine_xyz[3 * j + 2];
-            // bit f: the face neighbour f lists the triangle too (cells outside the grid are in the rim: not listed)
-            const int here = box_at(ix - 1, iy, iz) | box_at(ix + 1, iy, iz) << 1 | box_at(ix, iy - 1, iz) << 2 |
-                             box_at(ix, iy + 1, iz) << 3 | box_at(ix, iy, iz - 1) << 4 | box_at(ix, iy, iz + 1) << 5;
-            cells.push_back(mine[j]);
-            tris.push_back(t);
-            absent.push_back((unsigned char)(~here & 63));
-            for (int f = 0; f < 6; f++)
-                if (!((here >> f) & 1)) cnt[(size_t)mine[j] * CELL_STRIDE + f + 1]++;
-            cnt[(size_t)mine[j] * CELL_STRIDE + LIST_START + 1]++;
+                c0[a] = std::max(0, std::min(gn[a] - 1, (int)std::floor((l - g - (double)gmin[a]) / cs)));
+                c1[a] = std::max(0, std::min(gn[a] - 1, (int)std::floor((h + g - (double)gmin[a]) / cs)));
+            }
+            const double hh[3] = {0.5 * cs + g, 0.5 * cs + g, 0.5 * cs + g};
+            mine.clear();
+            mine_xyz.clear();
+            const int bx = c1[0] - c0[0] + 3, by = c1[1] - c0[1] + 3, bz = c1[2] - c0[2] + 3;
+            in_box.assign((size_t)bx * by * bz, 0);
+            auto box_at = [&](int ix, int iy, int iz) -> unsigned char & {
+                return in_box[((size_t)(iz - c0[2] + 1) * by + (iy - c0[1] + 1)) * bx + (ix - c0[0] + 1)];
+            };
+            for (int iz = c0[2]; iz <= c1[2]; iz++)
+                for (int iy = c0[1]; iy <= c1[1]; iy++)
+                    for (int ix = c0[0]; ix <= c1[0]; ix++) {
+                        const double cc[3] = {(double)gmin[0] + (ix + 0.5) * cs, (double)gmin[1] + (iy + 0.5) * cs,
+                                              (double)gmin[2] + (iz + 0.5) * cs};
+                        double a[3], b[3], c[3];
+                        for (int q = 0; q < 3; q++) {
+                            a[q] = (double)v[3 * t].pos[q] - cc[q];
+                            b[q] = (double)v[3 * t + 1].pos[q] - cc[q];
+                            c[q] = (double)v[3 * t + 2].pos[q] - cc[q];
+                        }
+                        if (!tri_box_overlap(a, b, c, hh)) continue;
+                        const uint32_t cell = (uint32_t)(((size_t)iz * gn[1] + iy) * gn[0] + ix);
+                        mine.push_back(cell);
+                        mine_xyz.push_back(ix); mine_xyz.push_back(iy); mine_xyz.push_back(iz);
+                        box_at(ix, iy, iz) = 1;
+                    }
+            for (size_t j = 0; j < mine.size(); j++) {
+                const int ix = mine_xyz[3 * j], iy = mine_xyz[3 * j + 1], iz = mine_xyz[3 * j + 2];
+                // bit f: the face neighbour f lists the triangle too (cells outside the grid are in the rim: not listed)
+                const int here = box_at(ix - 1, iy, iz) | box_at(ix + 1, iy, iz) << 1 | box_at(ix, iy - 1, iz) << 2 |
+                                 box_at(ix, iy + 1, iz) << 3 | box_at(ix, iy, iz - 1) << 4 | box_at(ix, iy, iz + 1) << 5;
+                P.cells.push_back(mine[j]);
+                P.tris.push_back(t);
+                P.absent.push_back((unsigned char)(~here & 63));
+            }
         }
+    };
+    if (n_threads == 1) {
+        file_run(0);
+    } else {
+        std::vector<std::thread> pool;
+        for (unsigned int part = 0; part < n_threads; part++) pool.emplace_back(file_run, part);
+        for (std::thread &th : pool) th.join();
+    }
+    for (const Part &P : parts) {
+        for (size_t i = 0; i < P.cells.size(); i++) {
+            const size_t at = (size_t)P.cells[i] * CELL_STRIDE;
+            for (int f = 0; f < 6; f++)
+                if ((P.absent[i] >> f) & 1) cnt[at + f + 1]++;
+            cnt[at + LIST_START + 1]++;
+        }
+        cells.insert(cells.end(), P.cells.begin(), P.cells.end());
+        tris.insert(tris.end(), P.tris.begin(), P.tris.end());
+        absent.insert(absent.end(), P.absent.begin(), P.absent.end());
     }
     // counts -> positions (slot 8 cell + 7 holds nothing of its own: it is where the next cell's lists start)
     for (size_t i = 0; i < ncell * CELL_STRIDE; i++) cnt[i + 1] += cnt[i];

@@ -18,7 +18,10 @@ frames = int(os.environ.get("FRAMES", "24"))
 dev = torch.device("cuda:0")
 ctxs = []
 for _ in range(max(ks)):
-    g = rt.RayTracer(wl["width"], wl["height"], options={"sweeps_in_turn": 1})
+    # OPTS="walk_budget=24,...": further options of the contexts (rt_set_option)
+    opts = {"sweeps_in_turn": 1}
+    opts.update((k, int(v)) for k, v in (kv.split("=") for kv in os.environ.get("OPTS", "").split(",") if kv))
+    g = rt.RayTracer(wl["width"], wl["height"], options=opts)
     setup_scene(g, wl)
     ctxs.append(g)
 for w in (1, world):
