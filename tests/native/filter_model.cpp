@@ -651,3 +651,86 @@ extern "C" void fm_check_walk_ranks(const float *gmin, float cs, const int *n, f
     }
     stats[0] = walks; stats[1] = states; stats[2] = bad; stats[3] = rounds; stats[4] = outside;
 }
+
+// ---------------------------------------------------------------------------------------------
+// The seven lists of every cell in space (rt_voxel.h).  Checked against their definition, cell by cell:
+// list 6 of a cell is exactly the set of triangles whose box / triangle test against the cell passes
+// (tested here once more, independently of the order the build files them in); list f (0..5) is exactly
+// list 6 without what list 6 of the face neighbour f holds (everything, when that neighbour is outside the
+// grid); a triangle stands on a list once; the offsets are those of the lists laid end to end.
+// stats: [0] cells [1] entries of all lists 6 [2] entries of all lists 0..5 [3] violations
+// ---------------------------------------------------------------------------------------------
+extern "C" void fm_check_cell_lists(int n_tris, const float *verts, const float *center, float radius, int voxel_res,
+                                    long long *stats)
+{
+    std::vector<rt_vertex> v((size_t)n_tris * 3);
+    for (int i = 0; i < n_tris * 3; i++) {
+        v[i] = rt_vertex{};
+        v[i].pos[0] = verts[3 * i]; v[i].pos[1] = verts[3 * i + 1]; v[i].pos[2] = verts[3 * i + 2];
+    }
+    rtc::ClusterSet cs;
+    rtc::build(v.data(), n_tris, center, radius, cs);
+    rtv::VoxelSet vs;
+    const double abs_extent = std::sqrt((double)center[0] * center[0] + (double)center[1] * center[1] +
+                                        (double)center[2] * center[2]) + 3.0 * (double)radius;
+    rtv::build(v.data(), n_tris, cs.rho, abs_extent, voxel_res, vs);
+    const rtv::Grid &G = vs.grid;
+    const long long ncell = (long long)G.nx * G.ny * G.nz;
+    long long bad = 0, full = 0, fresh = 0;
+    bad += (long long)vs.off.size() != ncell * rtv::CELL_STRIDE + 1 || vs.off[0] != 0u ||
+           vs.off.back() != (uint32_t)vs.entries.size();
+    auto list = [&](long long cell, int f) {
+        const uint32_t a = vs.off[(size_t)cell * rtv::CELL_STRIDE + f], b = vs.off[(size_t)cell * rtv::CELL_STRIDE + f + 1];
+        std::vector<int> out(vs.entries.begin() + a, vs.entries.begin() + b);
+        return out;
+    };
+    const double csz = (double)G.cs;
+#pragma omp parallel for schedule(dynamic, 64) reduction(+ : bad, full, fresh)
+    for (long long cell = 0; cell < ncell; cell++) {
+        const int ix = (int)(cell % G.nx), iy = (int)((cell / G.nx) % G.ny), iz = (int)(cell / ((long long)G.nx * G.ny));
+        bad += vs.off[(size_t)cell * rtv::CELL_STRIDE + 7] != vs.off[(size_t)(cell + 1) * rtv::CELL_STRIDE];
+        for (int f = 0; f <= rtv::CELL_LISTS; f++)
+            bad += vs.off[(size_t)cell * rtv::CELL_STRIDE + f] > vs.off[(size_t)cell * rtv::CELL_STRIDE + f + 1];
+        std::vector<int> all = list(cell, rtv::LIST_START);
+        full += (long long)all.size();
+        std::vector<int> sorted_all = all;
+        std::sort(sorted_all.begin(), sorted_all.end());
+        bad += std::adjacent_find(sorted_all.begin(), sorted_all.end()) != sorted_all.end();
+        // list 6 against the box / triangle test itself
+        const double cc[3] = {(double)G.gminx + (ix + 0.5) * csz, (double)G.gminy + (iy + 0.5) * csz,
+                              (double)G.gminz + (iz + 0.5) * csz};
+        for (int t : sorted_all) bad += t < 0 || t >= n_tris || !(cs.rho[t] >= 0.0);
+        if ((cell & 15) == 0) // (every 16th cell against every triangle: the test is the expensive part)
+            for (int t = 0; t < n_tris; t++) {
+                bool in = false;
+                if (cs.rho[t] >= 0.0) {
+                    const double g = cs.rho[t] + vs.margin;
+                    const double hh[3] = {0.5 * csz + g, 0.5 * csz + g, 0.5 * csz + g};
+                    double a[3], b[3], c[3];
+                    for (int q = 0; q < 3; q++) {
+                        a[q] = (double)v[3 * t].pos[q] - cc[q];
+                        b[q] = (double)v[3 * t + 1].pos[q] - cc[q];
+                        c[q] = (double)v[3 * t + 2].pos[q] - cc[q];
+                    }
+                    in = rtv::tri_box_overlap(a, b, c, hh);
+                }
+                bad += in != std::binary_search(sorted_all.begin(), sorted_all.end(), t);
+            }
+        for (int f = 0; f < 6; f++) {
+            const int a = f >> 1, step = (f & 1) ? 1 : -1;
+            const int jx = ix + (a == 0 ? step : 0), jy = iy + (a == 1 ? step : 0), jz = iz + (a == 2 ? step : 0);
+            std::vector<int> theirs;
+            if (jx >= 0 && jx < G.nx && jy >= 0 && jy < G.ny && jz >= 0 && jz < G.nz) {
+                theirs = list(((long long)jz * G.ny + jy) * G.nx + jx, rtv::LIST_START);
+                std::sort(theirs.begin(), theirs.end());
+            }
+            std::vector<int> want; // in the order of list 6
+            for (int t : all)
+                if (!std::binary_search(theirs.begin(), theirs.end(), t)) want.push_back(t);
+            const std::vector<int> got = list(cell, f);
+            fresh += (long long)got.size();
+            bad += got != want;
+        }
+    }
+    stats[0] = ncell; stats[1] = full; stats[2] = fresh; stats[3] = bad;
+}

@@ -873,3 +873,23 @@ def test_walk_by_rank_equals_walk_by_steps(fm):
             walks += st["walks"]
     assert total > 3_000_000
     assert rounds > 1.2 * walks   # walks of several rounds of 64 steps among them
+
+
+# -- the seven lists of a cell in space ----------------------------------------------------------
+@pytest.mark.parametrize("n_tris,res", [(600, 0), (3000, 12), (3000, 0), (40, 3)])
+def test_cell_lists_hold_what_is_new_behind_each_face(fm, n_tris, res):
+    """Every cell's list 6 is what the box / triangle test says, list f is list 6 without the face
+    neighbour's list 6, no triangle twice, offsets of lists laid end to end (rt_voxel.h, build)."""
+    rs = np.random.RandomState(77 + n_tris + res)
+    c = rs.uniform(-1, 1, (n_tris, 1, 3))
+    tris = (c + rs.uniform(-0.15, 0.15, (n_tris, 3, 3))).astype(np.float32)
+    tris[::17] = (c[::17] + rs.uniform(-0.6, 0.6, (len(c[::17]), 3, 3))).astype(np.float32)  # some large ones
+    tris = np.ascontiguousarray(tris.reshape(-1, 3))
+    center = np.zeros(3, dtype=np.float32)
+    stats = np.zeros(8, dtype=np.int64)
+    fm.fm_check_cell_lists.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p]
+    fm.fm_check_cell_lists(n_tris, tris.ctypes.data, center.ctypes.data, C.c_float(2.2), res, stats.ctypes.data)
+    cells, full, fresh, bad = (int(x) for x in stats[:4])
+    assert bad == 0, stats
+    assert cells > 0 and full > 0
+    assert fresh < 6 * full  # the lists of new triangles are shorter than the whole lists
