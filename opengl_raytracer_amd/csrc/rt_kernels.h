@@ -1751,6 +1751,7 @@ __global__ __launch_bounds__(BLOCK) void traverse_grid_kernel(TraverseParams p)
     // the rays as the reference arithmetic takes them: (origin, tmax), (direction, -)
     __shared__ float4 ray_o_all[BLOCK], ray_d_all[BLOCK];
     __shared__ unsigned int queue_all[(BLOCK / 64) * GRID_QCAP];
+    __shared__ float4 side_all[BLOCK]; // the rays of one cell side by side: scaled direction, lane (sweep_short)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = p.count ? *p.count : p.n;
@@ -1759,6 +1760,7 @@ __global__ __launch_bounds__(BLOCK) void traverse_grid_kernel(TraverseParams p)
     int *occl = occ_all + (ANYHIT ? wave * 64 : 0);
     float4 *ray_o = ray_o_all + wave * 64, *ray_d = ray_d_all + wave * 64;
     unsigned int *queue = queue_all + wave * GRID_QCAP;
+    float4 *side = side_all + wave * 64;
     // (the launch is laid out for the longest list there can be: wavefronts beyond the list's end leave at
     // once; a loop over groups here would cost the registers of an eighth wavefront per SIMD)
     const int s0 = (blockIdx.x * (BLOCK / 64) + wave) * R;
@@ -1887,6 +1889,49 @@ __global__ __launch_bounds__(BLOCK) void traverse_grid_kernel(TraverseParams p)
         }
     };
 
+    // Several rays at a time when the cell's list is short.  A list of at most 8 / 16 / 32 slots (with the slots
+    // that are on every list) leaves most lanes of a 64-slot read without a slot, and a camera or a light
+    // outside the mesh sees few triangles in a cell: there the list is read 8 / 4 / 2 times over, once per L
+    // lanes, the rays of the cell are laid side by side in LDS (direction and lane, in the order of their
+    // lanes), and every round tests 64 / L of them, each set of L lanes fetching its own.
+    auto sweep_short = [&](int log_l, const int *list, int cnt, const int *elist, int ecnt, unsigned long long group) {
+        const int sub = lane >> log_l, j = lane & ((1 << log_l) - 1); // L = 2^log_l lanes to a ray
+        int e = -1, tri = -1;
+        if (j < cnt) e = list[j];
+        else if (j < cnt + ecnt) e = elist[j - cnt];
+        float4 r0 = make_float4(qn, qn, qn, qn), r1 = r0, r2 = r0;
+        if (e >= 0) {
+            const float4 *rp = reinterpret_cast<const float4 *>(p.recs + e);
+            r0 = rp[0]; r1 = rp[1]; r2 = rp[2];
+            tri = p.tri_of[e];
+        }
+        if (tri < 0) r0.x = qn; // an empty slot: no ray passes a NaN record
+        const float rec[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
+        const int n_group = __popcll(group);
+        n_slow += n_group;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // (the last group's reads of the table are done)
+        __builtin_amdgcn_wave_barrier();
+        if ((group >> lane) & 1ull) side[lanes_below(group)] = make_float4(hx, hy, hz, __int_as_float(lane));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float4 ahead = side[sub];
+        for (int first = 0; first < n_group; first += 64 >> log_l) {
+            const int at = first + sub;
+            const float4 ray = ahead;
+            ahead = side[(at + (64 >> log_l)) & 63]; // (the next round's ray is on its way while this one is tested)
+            float lo, hi;
+            rtf::filter_origin_lohi(rec, ray.x, ray.y, ray.z, lo, hi);
+            const bool pass = at < n_group && fmaxf(lo, -hi) >= -1.0f;
+            const unsigned long long h = __builtin_amdgcn_ballot_w64(pass);
+            if (h) {
+                if (pass) queue[qcount + lanes_below(h)] = ((unsigned int)tri << 6) | (unsigned int)__float_as_int(ray.w);
+                qcount += __popcll(h);
+                if (qcount > GRID_QCAP - 64) drain(false);
+            }
+        }
+    };
+
     unsigned long long remaining = __builtin_amdgcn_ballot_w64(live && !wild);
     // the slots that are on every cell's list follow the cell's own
     const unsigned int every = 1u << (2 * p.grid_bits);
@@ -1899,7 +1944,11 @@ __global__ __launch_bounds__(BLOCK) void traverse_grid_kernel(TraverseParams p)
         remaining &= ~group;
         const unsigned int off = p.grid_off[c0];
         const int cnt = (int)(p.grid_off[c0 + 1] - off);
-        sweep(p.grid_entries + off, cnt, p.grid_entries + eoff, ecnt, group);
+        const int len = cnt + ecnt, n_group = __popcll(group);
+        if (len <= 16 ? n_group >= 3 : (len <= 32 && n_group >= 5))
+            sweep_short(len <= 8 ? 3 : (len <= 16 ? 4 : 5), p.grid_entries + off, cnt, p.grid_entries + eoff, ecnt, group);
+        else
+            sweep(p.grid_entries + off, cnt, p.grid_entries + eoff, ecnt, group);
     }
     const unsigned long long wilds = __builtin_amdgcn_ballot_w64(wild);
     if (wilds) sweep(nullptr, p.num_slots, nullptr, 0, wilds);
