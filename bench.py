@@ -194,6 +194,15 @@ def committed_counters(workload_name):
         return {}, None
 
 
+def committed_memory_path(workload_name):
+    """Per kernel: how busy the address units were, L1 hit rate, L2 round trip (tools/prof_memory_path.sh, committed)."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "memory_path_per_launch.json")))
+        return rec["kernels"] if rec.get("workload") == workload_name else {}
+    except (OSError, KeyError, ValueError):
+        return {}
+
+
 def named_launches(log, in_turn):
     """The kernel log as (rocprof kernel name, record) pairs.  A bounce pass is one record per kernel when
     its kernels run in turn, one record for all three when they run side by side on two streams."""
@@ -219,6 +228,7 @@ def kernel_rooflines(g, job, wl, workload_name):
     wave-instructions per launch (committed PMC summary) / live duration / issue peak -- which cannot
     exceed 1.  Second result: the shading epilogue of the color stage against the HBM roof."""
     counters, source = committed_counters(workload_name)
+    memory_path = committed_memory_path(workload_name)
     g.set_option("sweeps_in_turn", 1)
     g.set_option("kernel_timing", 1)
     try:
@@ -279,6 +289,9 @@ def kernel_rooflines(g, job, wl, workload_name):
                 # more instructions per second than the hardware can issue: the committed counters are those of
                 # another build of this kernel -- no fraction rather than a wrong one
                 entry.update(counters_source=source, counters_stale=True)
+        if memory_path.get(name):
+            # (from the committed counters of the vector memory path: not measured by this run)
+            entry["memory_path"] = memory_path[name]
         out.append(entry)
     return out, color
 
