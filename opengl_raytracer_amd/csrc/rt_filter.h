@@ -26,7 +26,7 @@
 //
 // Records are 12 floats (48 bytes) per triangle:
 //   general  : X[3], e1*sc[3], e2*sc[3], (e1*sc) x e2 [3]        sc = 2^-k, |e*sc| < 1
-//   origin O : ((Y-O) x (Z-O))*sc, ((Z-O) x (X-O))*sc, ((X-O) x (Y-O))*sc, 0,0,0
+//   origin O : ((Y-O) x (Z-O))*sc, ((Z-O) x (X-O))*sc, ((X-O) x (Y-O))*sc, (triangle index as bits on the device; 0), 0, 0
 // Cross products are formed in double and rounded once.  A triangle with
 // Y == X or Z == X (the reference can never accept it: a == 0) gets an all-NaN
 // record, which no ray passes.

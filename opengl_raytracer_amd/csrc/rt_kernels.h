@@ -195,6 +195,9 @@ __global__ __launch_bounds__(BLOCK) void prep_origin_kernel(const rt_vertex *__r
         rtf::make_origin_rec(v[3 * k].pos, v[3 * k + 1].pos, v[3 * k + 2].pos, O, &r);
         rtf::make_cone_rec(v[3 * k].pos, v[3 * k + 1].pos, v[3 * k + 2].pos, O, &r, extent, reach_max, &c);
     }
+    // (the record's three spare floats: the first carries the slot's triangle, so that the traversal that holds
+    // the record needs no second gather to name it)
+    r.v[9] = __int_as_float(k);
     out[i] = r;
     cones[i] = c;
 }
@@ -1858,7 +1861,7 @@ __global__ __launch_bounds__(BLOCK) void traverse_grid_kernel(TraverseParams p)
             if (e >= 0) {
                 const float4 *rp = reinterpret_cast<const float4 *>(p.recs + e);
                 r0 = rp[0]; r1 = rp[1]; r2 = rp[2];
-                tri = p.tri_of[e];
+                tri = __float_as_int(r2.y); // (prep_origin_kernel leaves the slot's triangle there)
             }
             if (tri < 0) r0.x = qn; // an empty slot: no ray passes a NaN record
             const float rec[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
@@ -1903,7 +1906,7 @@ __global__ __launch_bounds__(BLOCK) void traverse_grid_kernel(TraverseParams p)
         if (e >= 0) {
             const float4 *rp = reinterpret_cast<const float4 *>(p.recs + e);
             r0 = rp[0]; r1 = rp[1]; r2 = rp[2];
-            tri = p.tri_of[e];
+            tri = __float_as_int(r2.y);
         }
         if (tri < 0) r0.x = qn; // an empty slot: no ray passes a NaN record
         const float rec[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
