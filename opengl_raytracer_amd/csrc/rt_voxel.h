@@ -45,6 +45,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -445,7 +446,13 @@ inline void build(const rt_vertex *v, int num_tris, const std::vector<double> &r
         file_run(0);
     } else {
         std::vector<std::thread> pool;
-        for (unsigned int part = 0; part < n_threads; part++) pool.emplace_back(file_run, part);
+        unsigned int started = 0;
+        try {
+            for (; started < n_threads; started++) pool.emplace_back(file_run, started);
+        } catch (const std::system_error &) {
+            // (no more threads to be had: this one files the runs that are left)
+        }
+        for (unsigned int part = started; part < n_threads; part++) file_run(part);
         for (std::thread &th : pool) th.join();
     }
     for (const Part &P : parts) {
