@@ -338,6 +338,36 @@ def test_mesh_far_from_the_world_origin(rt, oracle_mod, offset):
         same("mesh at %r" % (offset,), g, c)
 
 
+# -- the cells in space are built by the first bounce pass ---------------------------------------------
+def test_cells_in_space_are_built_by_the_first_bounce_pass(rt, oracle_mod):
+    """rt_set_mesh leaves the cells that bounce rays walk to the first pass that needs them: frames of one
+    pass (camera and shadow rays only) never build them, a frame with bounces builds them once, another
+    mesh on the same context starts over, and so does a context whose cell size was changed before its
+    mesh was set again.  Every frame against the oracle."""
+    from opengl_raytracer_amd import scenes
+    w, h = 256, 160
+    meshes = [scenes.concat_meshes(scenes.triangle_soup(9000, seed=71, extent=0.9, size=0.07),
+                                   scenes.quad_grid(8, 8, origin=(-1.3, -1.0, -1.3), du=(2.6, 0, 0), dv=(0, 0, 2.6))),
+              scenes.triangle_soup(12000, seed=72, extent=1.0, size=0.05)]
+    cam = scenes.look_at_camera((0.3, 0.4, -2.8), (0.0, 0.0, 0.0))
+    lights = scenes.default_lights()
+    g, c = rt.RayTracer(w, h, options={"sort_min_rays": 4096}), oracle_mod.Oracle(w, h, threads=16)
+    with g:
+        for k, mesh in enumerate(meshes):
+            for o in (g, c):
+                o.set_mesh(mesh)
+                o.set_texture(scenes.noise_texture(32, 32))
+                o.set_lights(lights, 2)
+                o.set_camera(*cam)
+            for passes in (1, 1, 4, 2, 1, 3):
+                g.render(passes); c.render(passes)
+                same("mesh %d, %d passes" % (k, passes), g, c)
+        g.set_option("voxel_res", 20)   # (the mesh has to be set again after this option)
+        g.set_mesh(meshes[1])
+        g.render(3); c.render(3)
+        same("coarser cells", g, c)
+
+
 # -- a camera moved between raygen and intersect ------------------------------------------------------
 @pytest.mark.parametrize("mode,name", MODES[:2], ids=[m[1] for m in MODES[:2]])
 def test_camera_moved_after_raygen(rt, oracle_mod, mode, name):
