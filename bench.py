@@ -300,7 +300,7 @@ def exact_mode_roofline(g, job, wl):
     """The reference's loop as written (trace.glsl:135-157): the all-pairs mode -- every ray against every
     triangle, triangles staged in LDS tiles, no acceleration structure -- on every 8th row tile of the frame,
     two passes; its closest-hit launches against the FP32 vector peak.  `achieved` prices every pair at the 52
-    FLOP of the shader's test, as the survey's roofline does; the kernel executes 26 per pair (the shader's
+    FLOP of the shader's test, as a roofline of the brute-force loop does; the kernel executes 26 per pair (the shader's
     first 22 and a four-operation test that proves the shader's own early return) and the whole 52 only on the
     pairs that test leaves open, so `executed` is given beside it."""
     g.set_trace_mode(1)
