@@ -27,7 +27,8 @@ for _ in range(max(ks)):
 for w in (1, world):
     sharding._world = lambda w=w: (0, w)
     for k in ks:
-        job = sharding.TileShardedFrame(ctxs[:k], wl["width"], wl["height"], dev)
+        job = sharding.TileShardedFrame(ctxs[:k], wl["width"], wl["height"], dev,
+                                        tile_rows=int(os.environ["TILE_ROWS"]) if w > 1 and os.environ.get("TILE_ROWS") else None)
         job.gather = False
         for _ in range(k + 1):
             job.render(wl["passes"])
